@@ -1,0 +1,67 @@
+/*
+ * TEST INFRASTRUCTURE ONLY.  CPU checker interface for the alignment / minimizer hot path.
+ *
+ * Two shared libraries implement this same C interface:
+ *   oracle/libsa_oracle.so      - an independent CPU restatement of the reference algorithms
+ *                                 (oracle/oracle.cpp), built with g++ from this repository alone;
+ *   oracle/_ref/libsa_ref.so    - the reference's own alignment.cpp / minimizer*.cpp / utility.cpp
+ *                                 compiled where they lie (oracle/ref_wrap.cpp + oracle/Makefile),
+ *                                 available only where the reference checkout is mounted at build
+ *                                 time.
+ * Nothing in the shipped GPU path links, loads or calls either library: they are used by tests/,
+ * by the smoke check and by the CPU-baseline leg of the benchmark, as the checker / the timed CPU
+ * comparison, never as the thing measured as "GPU" or shipped.
+ */
+#ifndef SA_ORACLE_H
+#define SA_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* type: 0 Global (Needleman-Wunsch), 1 Local (Smith-Waterman), 2 Semiglobal; anything else -> 9999
+ * (reference src/alignment.h:25, src/alignment.cpp:353-374).
+ * cigar_buf may be NULL (no CIGAR requested; mirrors cigar == nullptr).  If non-NULL the compressed
+ * CIGAR is written NUL-terminated (at most cigar_cap bytes incl. NUL; *cigar_len gets the full length).
+ * target_begin may be NULL.  Returns the alignment score. */
+int sa_cpu_align(const char* query, uint32_t query_len, const char* target, uint32_t target_len,
+                 int type, int match, int mismatch, int gap,
+                 char* cigar_buf, size_t cigar_cap, size_t* cigar_len, uint32_t* target_begin);
+
+/* MinimizeBinary (reference src/minimizer_binary.cpp:136-178).  sequence must be NUL-terminated.
+ * Writes up to cap triples (value, position, strand) to out; returns the number of minimizers. */
+size_t sa_cpu_minimize_binary(const char* sequence, uint32_t sequence_len, uint32_t kmer_len,
+                              uint32_t window_len, uint32_t* out_triples, size_t cap);
+
+/* Minimize, decimal-string variant (reference src/minimizer.cpp:124-214).  Returns the number of
+ * minimizers, or (size_t)-1 when the reference would throw std::out_of_range from stoi. */
+size_t sa_cpu_minimize_decimal(const char* sequence, uint32_t sequence_len, uint32_t kmer_len,
+                               uint32_t window_len, uint32_t* out_triples, size_t cap);
+
+/* removeDuplicate (reference src/utility.cpp:8-26): sorts triples in place by (value, position,
+ * strand) and writes the de-duplicated list to out; returns its length. n must be >= 1. */
+size_t sa_cpu_remove_duplicate(uint32_t* triples, size_t n, uint32_t* out_triples);
+
+/* Task farm over independent pairs with `threads` std::threads - the stand-in for the reference's
+ * thread_pool dispatch (reference src/mapper.cpp:662-679).  Sequences are given as one blob plus
+ * n+1 offsets each.  scores/target_begin have n entries; cigar text is discarded after being built
+ * (want_cigar != 0 builds it, as the mapper does with -c). Returns 0. */
+int sa_cpu_align_batch(const char* q_blob, const uint64_t* q_off, const char* t_blob,
+                       const uint64_t* t_off, size_t n, int type, int match, int mismatch, int gap,
+                       int want_cigar, int threads, int32_t* scores, uint32_t* target_begin);
+
+/* Task farm over independent NUL-terminated sequences (seq i = blob + off[i], length len[i]).
+ * counts[i] receives the number of minimizers of sequence i.  Returns 0. */
+int sa_cpu_minimize_batch(const char* blob, const uint64_t* off, const uint32_t* len, size_t n,
+                          uint32_t kmer_len, uint32_t window_len, int threads, uint64_t* counts);
+
+/* "restatement" or "reference" */
+const char* sa_cpu_kind(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+"""ctypes binding of the CPU checkers (oracle/sa_oracle.h).  TEST INFRASTRUCTURE ONLY.
+
+`restatement()` loads oracle/libsa_oracle.so (built from oracle/oracle.cpp); `reference()` loads
+oracle/_ref/libsa_ref.so (the reference's own sources, compiled by oracle/Makefile) or returns None
+where that build is absent.  Both expose the same interface.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class CpuChecker:
+    def __init__(self, path):
+        self.lib = L = C.CDLL(path)
+        L.sa_cpu_align.restype = C.c_int
+        L.sa_cpu_align.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        for f in (L.sa_cpu_minimize_binary, L.sa_cpu_minimize_decimal):
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.sa_cpu_remove_duplicate.restype = C.c_size_t
+        L.sa_cpu_remove_duplicate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.sa_cpu_align_batch.restype = C.c_int
+        L.sa_cpu_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p]
+        L.sa_cpu_minimize_batch.restype = C.c_int
+        L.sa_cpu_minimize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.sa_cpu_kind.restype = C.c_char_p
+        self.kind = L.sa_cpu_kind().decode()
+
+    def align(self, query, target, type_, match, mismatch, gap, want_cigar=True,
+              want_target_begin=True):
+        """-> (score, cigar or None, target_begin or None)"""
+        q = query if isinstance(query, bytes) else query.encode()
+        t = target if isinstance(target, bytes) else target.encode()
+        cap = 2 * (len(q) + len(t)) + 32
+        buf = C.create_string_buffer(cap) if want_cigar else None
+        clen = C.c_size_t(0)
+        tb = C.c_uint32(0)
+        score = self.lib.sa_cpu_align(q, len(q), t, len(t), type_, match, mismatch, gap, buf,
+                                      cap if want_cigar else 0, C.byref(clen),
+                                      C.byref(tb) if want_target_begin else None)
+        return (score, buf.value.decode() if want_cigar else None,
+                tb.value if want_target_begin else None)
+
+    def _minimize(self, fn, seq, k, w):
+        s = seq if isinstance(seq, bytes) else seq.encode()
+        cap = max(len(s), 1)
+        out = np.zeros((cap, 3), dtype=np.uint32)
+        n = fn(s, len(s), k, w, out.ctypes.data, cap)
+        if n == C.c_size_t(-1).value:
+            return None
+        return [tuple(int(x) for x in row) for row in out[:n]]
+
+    def minimize_binary(self, seq, k, w):
+        return self._minimize(self.lib.sa_cpu_minimize_binary, seq, k, w)
+
+    def minimize_binary_array(self, seq, k, w):
+        """Same as minimize_binary but returns an (n, 3) uint32 array (for long sequences)."""
+        s = seq if isinstance(seq, bytes) else seq.encode()
+        out = np.zeros((max(len(s), 1), 3), dtype=np.uint32)
+        n = self.lib.sa_cpu_minimize_binary(s, len(s), k, w, out.ctypes.data, out.shape[0])
+        return out[:n].copy()
+
+    def minimize_decimal(self, seq, k, w):
+        """None where the reference throws from stoi."""
+        return self._minimize(self.lib.sa_cpu_minimize_decimal, seq, k, w)
+
+    def remove_duplicate(self, triples):
+        a = np.ascontiguousarray(np.asarray(triples, dtype=np.uint32).reshape(-1, 3))
+        out = np.zeros_like(a)
+        n = self.lib.sa_cpu_remove_duplicate(a.ctypes.data, a.shape[0], out.ctypes.data)
+        return [tuple(int(x) for x in r) for r in a], [tuple(int(x) for x in r) for r in out[:n]]
+
+    def align_batch(self, q_blob, q_off, t_blob, t_off, type_, match, mismatch, gap, want_cigar,
+                    threads):
+        """Blobs are uint8 arrays, offsets uint64 arrays of n+1 entries. -> (scores, target_begin)"""
+        n = len(q_off) - 1
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        scores = np.zeros(n, dtype=np.int32)
+        tb = np.zeros(n, dtype=np.uint32)
+        self.lib.sa_cpu_align_batch(q_blob.ctypes.data, q_off.ctypes.data, t_blob.ctypes.data,
+                                    t_off.ctypes.data, n, type_, match, mismatch, gap,
+                                    int(want_cigar), threads, scores.ctypes.data, tb.ctypes.data)
+        return scores, tb
+
+    def minimize_batch(self, blob, off, lens, k, w, threads):
+        n = len(lens)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        counts = np.zeros(n, dtype=np.uint64)
+        self.lib.sa_cpu_minimize_batch(blob.ctypes.data, off.ctypes.data, lens.ctypes.data, n, k, w,
+                                       threads, counts.ctypes.data)
+        return counts
+
+
+def _build(target):
+    subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
+
+
+_cache = {}
+
+
+def restatement():
+    if "r" not in _cache:
+        path = os.path.join(ORACLE_DIR, "libsa_oracle.so")
+        if not os.path.exists(path):
+            _build("all")
+        _cache["r"] = CpuChecker(path)
+    return _cache["r"]
+
+
+def reference():
+    """The compiled reference, or None where oracle/_ref was not built (it cannot be built without
+    the reference checkout, e.g. on the GPU box if the prebuilt file did not travel)."""
+    if "ref" not in _cache:
+        path = os.path.join(ORACLE_DIR, "_ref", "libsa_ref.so")
+        _cache["ref"] = CpuChecker(path) if os.path.exists(path) else None
+    return _cache["ref"]
