@@ -1,0 +1,173 @@
+/*
+ * C-ABI of the MI355X (gfx950) implementation of the SequenceAligner hot path:
+ * batched Align() (Needleman-Wunsch / Smith-Waterman / semi-global with CIGAR traceback) and batched
+ * Minimize()/MinimizeBinary() (k,w)-minimizer extraction.  Plain pointers and sizes only.
+ *
+ * The reference has no C interface of its own: its hot path is four C++ static libraries with free
+ * functions (reference src/alignment.h:1-36, src/minimizer.h:2-5, src/minimizer_binary.h:1-4,
+ * src/utility.h:1-2).  The C++ drop-in for those prototypes lives in include/alignment.h,
+ * include/minimizer.h, include/minimizer_binary.h and include/utility.h and is a thin layer over the
+ * functions below.  The batch functions take the place of the reference's one-task-per-read thread
+ * pool dispatch (reference src/mapper.cpp:662-679): a batch is a set of independent pairs / sequences.
+ *
+ * Every function returns 0 on success and a non-zero code on failure; sa_last_error() then returns a
+ * message for the calling thread.  Nothing here falls back to a CPU implementation: without a GPU the
+ * calls fail.
+ */
+#ifndef SA_HIP_H
+#define SA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* AlignmentType values, identical to the reference's plain enum (src/alignment.h:25). */
+enum { SA_GLOBAL = 0, SA_LOCAL = 1, SA_SEMIGLOBAL = 2 };
+
+/* Value returned as "score" for an unknown alignment type (reference src/alignment.cpp:371-373). */
+#define SA_UNKNOWN_TYPE_SCORE 9999
+
+/* CIGAR run encoding on the device: (length << 2) | op, op 0='M' 1='X' 2='I' 3='D'
+ * (same four letters as reference src/alignment.cpp:104-119). */
+#define SA_OP_M 0u
+#define SA_OP_X 1u
+#define SA_OP_I 2u
+#define SA_OP_D 3u
+
+/* Minimizer variants. SA_MIN_BINARY = MinimizeBinary (src/minimizer_binary.cpp:136-178),
+ * SA_MIN_DECIMAL = Minimize (src/minimizer.cpp:124-214). */
+enum { SA_MIN_BINARY = 0, SA_MIN_DECIMAL = 1 };
+
+/* Status codes. */
+enum {
+  SA_OK = 0,
+  SA_ERR_HIP = 1,          /* a HIP runtime call failed */
+  SA_ERR_ARGUMENT = 2,     /* invalid argument */
+  SA_ERR_WORKSPACE = 3,    /* workspace too small */
+  SA_ERR_NO_DEVICE = 4,    /* no usable GPU */
+  SA_ERR_RANGE = 5,        /* decimal Minimize: k-mer value exceeds INT_MAX (reference throws from stoi) */
+  SA_ERR_CAPACITY = 6      /* an output buffer is too small */
+};
+
+const char* sa_last_error(void);
+int sa_device_count(void);
+/* "gfx950..." name of the device's architecture, or NULL. */
+const char* sa_device_arch(int device);
+
+/* ---------------------------------------------------------------------------------------------
+ * Alignment, device-resident batch.  Takes the place of one Align() call per pair
+ * (reference src/alignment.cpp:353-374, called per read at src/mapper.cpp:423).
+ *
+ * Sequences: one byte per symbol (compared as opaque bytes, like target[i-1]==query[r-1] at
+ * src/alignment.cpp:63,176,281); pair p has query d_q[q_off[p] .. q_off[p+1]) and target
+ * d_t[t_off[p] .. t_off[p+1]).  All d_* pointers are device pointers on `device`; `stream` is a
+ * hipStream_t (NULL = default stream).  The call only enqueues work on the stream.
+ *
+ * Outputs (each may be NULL if not wanted, except d_score):
+ *   d_score[p]         alignment score
+ *   d_target_begin[p]  the value the reference stores in *target_begin (src/alignment.cpp:129-136,
+ *                      244-246, 342-348): Local = 0-based first target row; Global/Semiglobal = 3 if the
+ *                      CIGAR starts with a D-run of length <= 9, else 1
+ *   d_cigar_runs       n * cigar_stride uint32 run slots; pair p owns slots [p*stride, (p+1)*stride) and
+ *                      its runs, in forward (CIGAR text) order, end at the end of its slot range:
+ *                      first run at p*stride + stride - d_cigar_nruns[p].  Needs
+ *                      cigar_stride >= max_qlen + max_tlen (a run per op in the worst case).
+ *   d_cigar_nruns[p]   number of runs
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sa_align_batch {
+  const uint8_t* d_q;
+  const uint64_t* d_q_off; /* n + 1 entries */
+  const uint8_t* d_t;
+  const uint64_t* d_t_off; /* n + 1 entries */
+  uint32_t n;
+  uint32_t max_qlen; /* >= every query length in the batch */
+  uint32_t max_tlen; /* >= every target length in the batch */
+  int type;          /* SA_GLOBAL / SA_LOCAL / SA_SEMIGLOBAL */
+  int match, mismatch, gap;
+  int32_t* d_score;
+  uint32_t* d_target_begin;
+  uint32_t* d_cigar_runs;
+  uint32_t* d_cigar_nruns;
+  uint64_t cigar_stride;
+} sa_align_batch;
+
+/* Bytes of device scratch sa_align_batch_device needs for this batch shape (direction bits, strip
+ * boundary rows, per-pair end cells).  A smaller workspace is accepted as long as it holds at least one
+ * block of pairs: the batch is then processed in several passes.  *min_bytes (optional) receives that
+ * minimum. */
+size_t sa_align_workspace_bytes(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type,
+                                size_t* min_bytes);
+
+int sa_align_batch_device(int device, void* stream, const sa_align_batch* batch, void* d_workspace,
+                          size_t workspace_bytes);
+
+/* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32",
+ * "wavefront_i32", ...), for logs and profiles. */
+const char* sa_align_kernel_name(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type, int match,
+                                 int mismatch, int gap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Alignment, host buffers.  The device batch queue: pairs are split over `n_devices` GPUs
+ * (0 = all visible) by cost (query_len * target_len), staged through pinned buffers, aligned on each
+ * GPU's own stream and gathered back in input order - no inter-GPU communication.
+ * cigars (optional) receives n malloc'ed NUL-terminated CIGAR strings, "<count><op>..." exactly as
+ * CompressCigar prints them (src/alignment.cpp:17-33); free each with sa_free().
+ * ------------------------------------------------------------------------------------------- */
+int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
+                        const char* const* targets, const uint32_t* target_lens, size_t n, int type,
+                        int match, int mismatch, int gap, int n_devices, int32_t* scores,
+                        uint32_t* target_begin, char** cigars);
+void sa_free(void* p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Minimizers, device-resident batch.  Takes the place of one MinimizeBinary()/Minimize() call per
+ * sequence (reference src/minimizer_binary.cpp:136-178, called at src/mapper.cpp:179).
+ *
+ * Sequence s is d_seq[off[s] .. off[s+1]) (ASCII, ACGT in either case).  Output: for each sequence its
+ * minimizers sorted by (value, position, strand) with duplicates removed (reference
+ * src/utility.cpp:8-26), as uint32 triples {value, position, strand(1 = forward, 0 = other strand)};
+ * sequence s owns triples [d_out_off[s], d_out_off[s+1]) of d_out.  out_capacity is in triples;
+ * sa_minimize_out_capacity() gives a sufficient value.  d_status (one int, optional) receives SA_OK,
+ * SA_ERR_CAPACITY or SA_ERR_RANGE, written by the device when the work completes.
+ * Requires 1 <= k <= 16, 1 <= w <= k + 1 and every length >= k + w - 1 (outside that the reference reads
+ * out of bounds; the call is rejected with SA_ERR_ARGUMENT).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sa_minimize_batch {
+  const uint8_t* d_seq;
+  const uint64_t* d_off; /* n + 1 entries */
+  uint32_t n;
+  uint64_t total_len; /* == off[n] */
+  uint32_t max_len;
+  uint32_t min_len;
+  uint32_t k, w;
+  int variant; /* SA_MIN_BINARY / SA_MIN_DECIMAL */
+  uint32_t* d_out;
+  uint64_t out_capacity;
+  uint64_t* d_out_off; /* n + 1 entries */
+  int* d_status;
+} sa_minimize_batch;
+
+size_t sa_minimize_workspace_bytes(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k,
+                                   uint32_t w, int variant);
+uint64_t sa_minimize_out_capacity(uint32_t n, uint64_t total_len, uint32_t k, uint32_t w);
+
+int sa_minimize_batch_device(int device, void* stream, const sa_minimize_batch* batch,
+                             void* d_workspace, size_t workspace_bytes);
+
+/* Minimizers, host buffers, sequences split over n_devices GPUs by length (0 = all visible).
+ * out_triples[s] receives a malloc'ed array of out_counts[s] triples (free with sa_free). */
+int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t n, uint32_t k,
+                           uint32_t w, int variant, int n_devices, uint32_t** out_triples,
+                           uint64_t* out_counts);
+
+/* removeDuplicate on the device (reference src/utility.cpp:8-26): sorts n triples in place by
+ * (value, position, strand) and writes the distinct ones to out (capacity n); *out_n = their number. */
+int sa_remove_duplicate_host(uint32_t* triples, size_t n, uint32_t* out, size_t* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

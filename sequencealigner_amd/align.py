@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's alignment interface over the C-ABI (include/sa_hip.h).
+
+`Align()` has the argument meaning of the reference's Align() (src/alignment.h:28-36):
+query/target with explicit lengths, an AlignmentType, match/mismatch/gap, and the two optional
+outputs cigar and target_begin.  `DeviceAlignBatch` is the resident-batch form used for throughput
+work: the inputs live in HBM, `run()` only enqueues kernels.
+
+torch is used for device memory and streams only.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+import torch
+
+from . import capi
+
+_OPS = "MXID"
+
+
+class AlignmentType(enum.IntEnum):
+    """Same values as the reference's plain enum AlignmentType (src/alignment.h:25)."""
+    Global = 0
+    Local = 1
+    Semiglobal = 2
+
+
+def _as_u8(x):
+    if isinstance(x, str):
+        x = x.encode()
+    if isinstance(x, (bytes, bytearray)):
+        return np.frombuffer(bytes(x), dtype=np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def runs_to_cigar(runs):
+    """uint32 runs ((len << 2) | op) -> "<count><op>..." as CompressCigar prints it
+    (src/alignment.cpp:17-33: the count is always printed, including 1)."""
+    return "".join(f"{int(v) >> 2}{_OPS[int(v) & 3]}" for v in runs)
+
+
+class DeviceAlignBatch:
+    """A batch of independent pairs resident on one GPU.
+
+    queries/targets: either (n, L) uint8 arrays (uniform length) or lists of byte strings/arrays.
+    """
+
+    def __init__(self, queries, targets, type_, match, mismatch, gap, want_cigar=True,
+                 want_target_begin=True, device=0, workspace_bytes=None):
+        from . import synth
+        self.lib = capi.lib()
+        self.device = torch.device("cuda", device)
+        self.dev_index = device
+        qb, qo = synth.to_blob(queries if isinstance(queries, np.ndarray) else [_as_u8(x) for x in queries])
+        tb, to = synth.to_blob(targets if isinstance(targets, np.ndarray) else [_as_u8(x) for x in targets])
+        self.n = len(qo) - 1
+        assert len(to) - 1 == self.n
+        qlens = np.diff(qo.astype(np.int64))
+        tlens = np.diff(to.astype(np.int64))
+        self.qlens, self.tlens = qlens, tlens
+        self.max_q = int(qlens.max()) if self.n else 0
+        self.max_t = int(tlens.max()) if self.n else 0
+        self.cells = int((qlens * tlens).sum())
+        self.type, self.match, self.mismatch, self.gap = int(type_), int(match), int(mismatch), int(gap)
+
+        def dev(a, dtype):
+            t = torch.from_numpy(np.ascontiguousarray(a).view(dtype) if a.size else np.zeros(1, dtype))
+            return t.to(self.device)
+
+        # +8 bytes of slack so that kernels may read whole dwords at the end of the blob
+        self.d_q = dev(np.concatenate([qb, np.zeros(8, np.uint8)]), np.uint8)
+        self.d_t = dev(np.concatenate([tb, np.zeros(8, np.uint8)]), np.uint8)
+        self.d_qo = dev(qo.astype(np.uint64).view(np.int64), np.int64)
+        self.d_to = dev(to.astype(np.uint64).view(np.int64), np.int64)
+        n1 = max(self.n, 1)
+        self.d_score = torch.zeros(n1, dtype=torch.int32, device=self.device)
+        self.d_tb = torch.zeros(n1, dtype=torch.int32, device=self.device) if want_target_begin else None
+        self.stride = self.max_q + self.max_t
+        if want_cigar:
+            self.d_runs = torch.zeros(max(n1 * self.stride, 1), dtype=torch.int32, device=self.device)
+            self.d_nruns = torch.zeros(n1, dtype=torch.int32, device=self.device)
+        else:
+            self.d_runs = self.d_nruns = None
+        min_bytes = C.c_size_t(0)
+        full = self.lib.sa_align_workspace_bytes(self.n, self.max_q, self.max_t, self.type,
+                                                 C.byref(min_bytes))
+        if workspace_bytes is None:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            workspace_bytes = min(full, max(min_bytes.value, int(free * 0.6)))
+        self.workspace_bytes = max(int(workspace_bytes), min_bytes.value)
+        self.d_ws = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+        self.batch = capi.AlignBatch(
+            self.d_q.data_ptr(), self.d_qo.data_ptr(), self.d_t.data_ptr(), self.d_to.data_ptr(),
+            self.n, self.max_q, self.max_t, self.type, self.match, self.mismatch, self.gap,
+            self.d_score.data_ptr(), self.d_tb.data_ptr() if self.d_tb is not None else None,
+            self.d_runs.data_ptr() if self.d_runs is not None else None,
+            self.d_nruns.data_ptr() if self.d_nruns is not None else None, self.stride)
+
+    def kernel_name(self):
+        return self.lib.sa_align_kernel_name(self.n, self.max_q, self.max_t, self.type, self.match,
+                                             self.mismatch, self.gap).decode()
+
+    def run(self, stream=None):
+        """Enqueue the whole batch on `stream` (a torch.cuda.Stream; default: the current stream)."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        capi.check(self.lib.sa_align_batch_device(self.dev_index, C.c_void_p(s.cuda_stream),
+                                                  C.byref(self.batch), C.c_void_p(self.d_ws.data_ptr()),
+                                                  self.workspace_bytes))
+
+    def scores(self):
+        return self.d_score[:self.n].cpu().numpy()
+
+    def target_begins(self):
+        return self.d_tb[:self.n].cpu().numpy().view(np.uint32)
+
+    def cigars(self, indices=None):
+        """CIGAR strings of the given pairs (default: all)."""
+        nruns = self.d_nruns[:self.n].cpu().numpy()
+        idx = range(self.n) if indices is None else indices
+        out = []
+        if indices is None:
+            runs = self.d_runs.cpu().numpy().view(np.uint32)
+            for p in idx:
+                e = (p + 1) * self.stride
+                out.append(runs_to_cigar(runs[e - nruns[p]:e]))
+        else:
+            for p in idx:
+                e = (p + 1) * self.stride
+                out.append(runs_to_cigar(self.d_runs[e - int(nruns[p]):e].cpu().numpy().view(np.uint32)))
+        return out
+
+
+def align_batch(queries, targets, type_, match, mismatch, gap, want_cigar=True, device=0):
+    """-> (scores int32[n], cigars list[str] or None, target_begin uint32[n])"""
+    b = DeviceAlignBatch(queries, targets, type_, match, mismatch, gap, want_cigar, True, device)
+    b.run()
+    torch.cuda.synchronize(b.device)
+    return b.scores(), (b.cigars() if want_cigar else None), b.target_begins()
+
+
+def Align(query, query_len, target, target_len, type_, match, mismatch, gap, want_cigar=True,
+          want_target_begin=True, device=0):
+    """Mirror of the reference Align() (src/alignment.cpp:353-374).
+
+    Returns (score, cigar or None, target_begin or None).  An unknown type returns 9999 like the
+    reference.  With want_cigar=False and want_target_begin=True, Global/Semiglobal report
+    target_begin = 1 (the reference inspects an empty CIGAR string there).
+    """
+    if int(type_) not in (0, 1, 2):
+        return capi.SA_UNKNOWN_TYPE_SCORE, None, None
+    q = _as_u8(query)[:query_len]
+    t = _as_u8(target)[:target_len]
+    scores, cigars, tb = align_batch([q], [t], type_, match, mismatch, gap, want_cigar, device)
+    tbv = None
+    if want_target_begin:
+        tbv = int(tb[0]) if (want_cigar or int(type_) == AlignmentType.Local) else 1
+    return int(scores[0]), (cigars[0] if want_cigar else None), tbv

@@ -1,0 +1,153 @@
+"""GPU parity tests for batched Align(): the HIP path (through the C-ABI) against the golden fixtures
+produced by the compiled reference and against the CPU restatement on seeded inputs.  Bit-exact bar:
+score, CIGAR string and target_begin must all be identical."""
+import random
+
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+SCHEMES = [(1, -1, -1), (2, -2, -1), (0, -1, -1), (2, -1, -1), (1, -3, -2), (1, 1, -1), (1, -1, 0),
+           (1, -1, 1)]
+
+
+def _run_group(cases):
+    """cases: list of dicts sharing (type, match, mismatch, gap). Runs them as ONE ragged batch."""
+    from sequencealigner_amd import align
+    if not cases:
+        return
+    c0 = cases[0]
+    scores, cigars, tb = align.align_batch([c["q"] for c in cases], [c["t"] for c in cases], c0["type"],
+                                           c0["match"], c0["mismatch"], c0["gap"])
+    for c, s, cg, b in zip(cases, scores, cigars, tb):
+        assert (int(s), cg, int(b)) == (c["score"], c["cigar"], c["target_begin"]), \
+            (c["q"], c["t"], c["type"], c["match"], c["mismatch"], c["gap"])
+
+
+def _grouped(cases):
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["type"], c["match"], c["mismatch"], c["gap"]), []).append(c)
+    return groups.values()
+
+
+def test_golden_align_cases():
+    n = 0
+    for g in _grouped(golden_io.load("align_cases.json")):
+        _run_group(g)
+        n += len(g)
+    assert n > 500
+
+
+def test_golden_benchmark_shapes():
+    for g in _grouped(golden_io.load("align_shapes.json")):
+        _run_group(g)
+
+
+def test_single_call_mirror():
+    from sequencealigner_amd.align import Align, AlignmentType
+    # reference unit tests (test/testAlignmentMinimizer.cpp:14,24,34) assert these scores
+    assert Align("CTCTGTTCG", 9, "CGTATCTTGA", 10, AlignmentType.Global, 0, -1, -1)[0] == -5
+    assert Align("CTCTGAG", 7, "TGTCAGT", 7, AlignmentType.Local, 2, -2, -1)[0] == 6
+    assert Align("AGCATGCAAT", 10, "ATCCGAACATCCAATCGAAGC", 21, AlignmentType.Semiglobal, 2, -1, -1)[0] == 14
+    assert Align("ACGT", 4, "ACGT", 4, 7, 1, -1, -1)[0] == 9999
+    # explicit lengths shorter than the buffers
+    assert Align("ACGTTTTT", 4, "TTTACGTAAAA", 7, AlignmentType.Global, 1, -1, -1) == (1, "3D4M", 3)
+    assert Align("ACGT", 4, "TTACGT", 6, AlignmentType.Local, 1, -1, -1, want_cigar=False) == (4, None, 2)
+
+
+def _oracle_cases(oracle, pairs, typ, m, x, g):
+    out = []
+    for q, t in pairs:
+        s, cg, tb = oracle.align(q, t, typ, m, x, g)
+        if typ == 1 and s <= 0:
+            continue
+        if typ == 2 and s <= 0 and g <= 0:
+            continue
+        out.append({"q": q, "t": t, "type": typ, "match": m, "mismatch": x, "gap": g, "score": s,
+                    "cigar": cg, "target_begin": tb})
+    return out
+
+
+def test_ragged_random_vs_oracle(oracle):
+    rng = random.Random(4242)
+    pairs = []
+    for _ in range(700):
+        alpha = rng.choice(["ACGT", "ACGT", "AC", "ACGTN"])
+        T = rng.randint(1, 200)
+        t = "".join(rng.choice(alpha) for _ in range(T))
+        if rng.random() < 0.6:
+            cut = t[rng.randint(0, T // 2):rng.randint(T // 2 + 1, T + 1)]
+            q = "".join(c if rng.random() > 0.12 else rng.choice(alpha) for c in cut) or "A"
+            if rng.random() < 0.5:
+                k = rng.randint(0, len(q))
+                q = q[:k] + "".join(rng.choice(alpha) for _ in range(rng.randint(1, 5))) + q[k:]
+        else:
+            q = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 200)))
+        pairs.append((q, t))
+    n = 0
+    for (m, x, g) in SCHEMES:
+        for typ in (0, 1, 2):
+            cases = _oracle_cases(oracle, pairs, typ, m, x, g)
+            _run_group(cases)
+            n += len(cases)
+    assert n > 10000
+
+
+def test_uniform_shapes_vs_oracle(oracle):
+    from sequencealigner_amd import synth
+    q, t = synth.pairs_short_read_window(300, seed=5)
+    pairs = [(bytes(a).decode(), bytes(b).decode()) for a, b in zip(q, t)]
+    for typ in (0, 1, 2):
+        _run_group(_oracle_cases(oracle, pairs, typ, 1, -1, -1))
+    q, t = synth.pairs_global_1k(70, seed=6, length=400)
+    pairs = [(bytes(a).decode(), bytes(b).decode()) for a, b in zip(q, t)]
+    for typ in (0, 1, 2):
+        _run_group(_oracle_cases(oracle, pairs, typ, 2, -3, -2))
+
+
+def test_small_workspace_multiple_passes(oracle):
+    """A workspace that holds one block of pairs forces several passes; results must not change."""
+    import ctypes as C
+    from sequencealigner_amd import align, capi, synth
+    q, t = synth.pairs_short_read_window(700, seed=8, read_len=60, window_len=90)
+    mb = C.c_size_t(0)
+    capi.lib().sa_align_workspace_bytes(700, 60, 90, 1, C.byref(mb))
+    b = align.DeviceAlignBatch(q, t, 1, 1, -1, -1, workspace_bytes=mb.value)
+    b.run()
+    import torch
+    torch.cuda.synchronize()
+    s, cg, tb = b.scores(), b.cigars(), b.target_begins()
+    for i in range(0, 700, 7):
+        assert (int(s[i]), cg[i], int(tb[i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
+
+
+def test_full_size_properties():
+    """Full benchmark size (scaled to 200k pairs to bound the time): every CIGAR must re-score to the
+    reported score and consume exactly the aligned part of query and target."""
+    import torch
+    from sequencealigner_amd import align, synth
+    n = 200_000
+    q, t = synth.pairs_short_read_window(n, seed=9)
+    b = align.DeviceAlignBatch(q, t, 1, 1, -1, -1)
+    b.run()
+    torch.cuda.synchronize()
+    scores = b.scores()
+    nruns = b.d_nruns[:n].cpu().numpy()
+    runs = b.d_runs.cpu().numpy().view(np.uint32).reshape(n, b.stride)
+    assert scores.min() > 100 and scores.max() <= 150
+    # re-score from runs: M -> +1, X/I/D -> -1
+    col = np.arange(b.stride)[None, :]
+    valid = col >= (b.stride - nruns)[:, None]
+    length = (runs >> 2).astype(np.int64) * valid
+    op = runs & 3
+    rescored = (length * np.where(op == 0, 1, -1)).sum(axis=1)
+    assert np.array_equal(rescored, scores)
+    q_used = (length * ((op == 0) | (op == 1) | (op == 2))).sum(axis=1)
+    t_used = (length * ((op == 0) | (op == 1) | (op == 3))).sum(axis=1)
+    assert q_used.max() <= 150 and t_used.max() <= 300
+    tb = b.target_begins().astype(np.int64)
+    assert ((tb + t_used) <= 300).all()
