@@ -109,6 +109,14 @@ int sa_align_batch_device(int device, void* stream, const sa_align_batch* batch,
 const char* sa_align_kernel_name(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type, int match,
                                  int mismatch, int gap);
 
+/* Kernel timing for benchmarks (no counterpart in the reference).  While enabled, every
+ * sa_align_batch_device call on this process brackets its kernels with HIP events on the call's own
+ * stream; sa_align_profile_read() synchronises those events and returns the accumulated
+ * milliseconds and launch counts per kernel class since the last read: index 0 = sequence packing,
+ * 1 = DP fill, 2 = traceback.  Not thread-safe; meant for one benchmarking thread. */
+int sa_align_profile(int enable);
+int sa_align_profile_read(double ms[3], uint64_t launches[3]);
+
 /* ---------------------------------------------------------------------------------------------
  * Alignment, host buffers.  The device batch queue: pairs are split over `n_devices` GPUs
  * (0 = all visible) by cost (query_len * target_len), staged through pinned buffers, aligned on each

@@ -2,6 +2,8 @@
 #include "align_common.h"
 #include "align_lane_i32.h"
 
+#include <vector>
+
 namespace sa {
 
 std::string& last_error() {
@@ -53,15 +55,48 @@ Plan make_plan(uint32_t /*n*/, uint32_t max_q, uint32_t max_t, int /*type*/, int
   return pl;
 }
 
+// ---- optional kernel timing (sa_align_profile) ---------------------------------------------------
+struct Span {
+  hipEvent_t a, b;
+  int cls;
+};
+bool g_profile = false;
+std::vector<Span> g_spans;
+
+struct Timed {
+  hipStream_t stream;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timed(hipStream_t s, int c) : stream(s), cls(c) {
+    if (!g_profile) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      a = b = nullptr;
+      return;
+    }
+    (void)hipEventRecord(a, stream);
+  }
+  ~Timed() {
+    if (!a) return;
+    (void)hipEventRecord(b, stream);
+    g_spans.push_back({a, b, cls});
+  }
+};
+
 template <int MODE>
 int launch_pass(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
   const uint32_t blocks = (a.pairs_in_pass + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL((fill_lane_i32<MODE, kLaneI32K>), dim3(blocks), dim3(kBlock), 0, stream, a);
+  {
+    Timed tm(stream, 1);
+    hipLaunchKernelGGL((fill_lane_i32<MODE, kLaneI32K>), dim3(blocks), dim3(kBlock), 0, stream, a);
+  }
   SA_HIP_TRY(hipGetLastError());
   if (need_traceback) {
     LaneI32Layout<kLaneI32K> lay{a.dirs, a.dirs_unit_stride, a.max_q ? a.max_q : 1};
-    hipLaunchKernelGGL((traceback_kernel<MODE, LaneI32Layout<kLaneI32K>>), dim3(blocks), dim3(kBlock),
-                       0, stream, a, lay);
+    {
+      Timed tm(stream, 2);
+      hipLaunchKernelGGL((traceback_kernel<MODE, LaneI32Layout<kLaneI32K>>), dim3(blocks),
+                         dim3(kBlock), 0, stream, a, lay);
+    }
     SA_HIP_TRY(hipGetLastError());
   }
   (void)pl;
@@ -89,6 +124,29 @@ const char* sa_device_arch(int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
   snprintf(name, sizeof name, "%s", prop.gcnArchName);
   return name;
+}
+
+int sa_align_profile(int enable) {
+  g_profile = enable != 0;
+  return SA_OK;
+}
+
+int sa_align_profile_read(double ms[3], uint64_t launches[3]) {
+  for (int i = 0; i < 3; ++i) {
+    ms[i] = 0;
+    launches[i] = 0;
+  }
+  for (Span& sp : g_spans) {
+    float t = 0;
+    SA_HIP_TRY(hipEventSynchronize(sp.b));
+    SA_HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
+    ms[sp.cls] += t;
+    launches[sp.cls] += 1;
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  g_spans.clear();
+  return SA_OK;
 }
 
 size_t sa_align_workspace_bytes(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type,
