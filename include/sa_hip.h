@@ -85,6 +85,8 @@ typedef struct sa_align_batch {
   uint32_t n;
   uint32_t max_qlen; /* >= every query length in the batch */
   uint32_t max_tlen; /* >= every target length in the batch */
+  uint32_t min_qlen; /* <= every query length (0 = unknown); min == max lets equal-length kernels run */
+  uint32_t min_tlen; /* <= every target length (0 = unknown) */
   int type;          /* SA_GLOBAL / SA_LOCAL / SA_SEMIGLOBAL */
   int match, mismatch, gap;
   int32_t* d_score;
@@ -94,20 +96,18 @@ typedef struct sa_align_batch {
   uint64_t cigar_stride;
 } sa_align_batch;
 
-/* Bytes of device scratch sa_align_batch_device needs for this batch shape (direction bits, strip
- * boundary rows, per-pair end cells).  A smaller workspace is accepted as long as it holds at least one
+/* Bytes of device scratch sa_align_batch_device needs for this batch (direction bits, strip boundary
+ * rows, repacked sequences, per-pair end cells); only the shape and scoring fields of `batch` are read.  A smaller workspace is accepted as long as it holds at least one
  * block of pairs: the batch is then processed in several passes.  *min_bytes (optional) receives that
  * minimum. */
-size_t sa_align_workspace_bytes(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type,
-                                size_t* min_bytes);
+size_t sa_align_workspace_bytes(const sa_align_batch* batch, size_t* min_bytes);
 
 int sa_align_batch_device(int device, void* stream, const sa_align_batch* batch, void* d_workspace,
                           size_t workspace_bytes);
 
 /* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32",
  * "wavefront_i32", ...), for logs and profiles. */
-const char* sa_align_kernel_name(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type, int match,
-                                 int mismatch, int gap);
+const char* sa_align_kernel_name(const sa_align_batch* batch);
 
 /* Kernel timing for benchmarks (no counterpart in the reference).  While enabled, every
  * sa_align_batch_device call on this process brackets its kernels with HIP events on the call's own

@@ -81,24 +81,25 @@ class DeviceAlignBatch:
             self.d_nruns = torch.zeros(n1, dtype=torch.int32, device=self.device)
         else:
             self.d_runs = self.d_nruns = None
+        self.min_q = int(qlens.min()) if self.n else 0
+        self.min_t = int(tlens.min()) if self.n else 0
+        self.batch = capi.AlignBatch(
+            self.d_q.data_ptr(), self.d_qo.data_ptr(), self.d_t.data_ptr(), self.d_to.data_ptr(),
+            self.n, self.max_q, self.max_t, self.min_q, self.min_t, self.type, self.match,
+            self.mismatch, self.gap,
+            self.d_score.data_ptr(), self.d_tb.data_ptr() if self.d_tb is not None else None,
+            self.d_runs.data_ptr() if self.d_runs is not None else None,
+            self.d_nruns.data_ptr() if self.d_nruns is not None else None, self.stride)
         min_bytes = C.c_size_t(0)
-        full = self.lib.sa_align_workspace_bytes(self.n, self.max_q, self.max_t, self.type,
-                                                 C.byref(min_bytes))
+        full = self.lib.sa_align_workspace_bytes(C.byref(self.batch), C.byref(min_bytes))
         if workspace_bytes is None:
             free, _ = torch.cuda.mem_get_info(self.device)
             workspace_bytes = min(full, max(min_bytes.value, int(free * 0.6)))
         self.workspace_bytes = max(int(workspace_bytes), min_bytes.value)
         self.d_ws = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
-        self.batch = capi.AlignBatch(
-            self.d_q.data_ptr(), self.d_qo.data_ptr(), self.d_t.data_ptr(), self.d_to.data_ptr(),
-            self.n, self.max_q, self.max_t, self.type, self.match, self.mismatch, self.gap,
-            self.d_score.data_ptr(), self.d_tb.data_ptr() if self.d_tb is not None else None,
-            self.d_runs.data_ptr() if self.d_runs is not None else None,
-            self.d_nruns.data_ptr() if self.d_nruns is not None else None, self.stride)
 
     def kernel_name(self):
-        return self.lib.sa_align_kernel_name(self.n, self.max_q, self.max_t, self.type, self.match,
-                                             self.mismatch, self.gap).decode()
+        return self.lib.sa_align_kernel_name(C.byref(self.batch)).decode()
 
     def run(self, stream=None):
         """Enqueue the whole batch on `stream` (a torch.cuda.Stream; default: the current stream)."""

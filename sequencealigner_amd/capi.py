@@ -25,6 +25,7 @@ class AlignBatch(C.Structure):
     _fields_ = [
         ("d_q", C.c_void_p), ("d_q_off", C.c_void_p), ("d_t", C.c_void_p), ("d_t_off", C.c_void_p),
         ("n", C.c_uint32), ("max_qlen", C.c_uint32), ("max_tlen", C.c_uint32),
+        ("min_qlen", C.c_uint32), ("min_tlen", C.c_uint32),
         ("type", C.c_int), ("match", C.c_int), ("mismatch", C.c_int), ("gap", C.c_int),
         ("d_score", C.c_void_p), ("d_target_begin", C.c_void_p), ("d_cigar_runs", C.c_void_p),
         ("d_cigar_nruns", C.c_void_p), ("cigar_stride", C.c_uint64),
@@ -45,12 +46,10 @@ SYMBOLS = [
     ("sa_last_error", C.c_char_p, []),
     ("sa_device_count", C.c_int, []),
     ("sa_device_arch", C.c_char_p, [C.c_int]),
-    ("sa_align_workspace_bytes", C.c_size_t,
-     [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_size_t)]),
+    ("sa_align_workspace_bytes", C.c_size_t, [C.POINTER(AlignBatch), C.POINTER(C.c_size_t)]),
     ("sa_align_batch_device", C.c_int,
      [C.c_int, C.c_void_p, C.POINTER(AlignBatch), C.c_void_p, C.c_size_t]),
-    ("sa_align_kernel_name", C.c_char_p,
-     [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("sa_align_kernel_name", C.c_char_p, [C.POINTER(AlignBatch)]),
     ("sa_align_profile", C.c_int, [C.c_int]),
     ("sa_align_profile_read", C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("sa_align_batch_host", C.c_int,

@@ -1,7 +1,10 @@
 // Device-resident batched Align(): workspace planning, kernel choice and launches.
 #include "align_common.h"
 #include "align_lane_i32.h"
+#include "align_lane_pk16.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace sa {
@@ -23,34 +26,98 @@ int fail(int code, const char* fmt, ...) {
 
 namespace {
 
-constexpr int kLaneI32K = 32;      // target rows per register strip of the 32-bit lane kernel
-constexpr uint32_t kBlock = 256;   // threads per workgroup of the lane kernels
+constexpr int kLaneI32K = 32;     // target rows per register strip of the 32-bit lane kernel
+constexpr uint32_t kBlock = 256;  // threads per workgroup of the lane kernels
 
-enum class Family { LaneI32 };
+enum class Family { LaneI32, LanePk16 };
 
 struct Plan {
   Family family;
+  int K;                      // rows per strip
   uint32_t nstrips;
-  uint64_t dirs_unit_stride;  // dwords per unit (wave)
+  uint32_t t_pad;             // nstrips * K
+  uint32_t bias;              // packed kernels: score offset
+  uint32_t pairs_per_unit;    // pairs per wave
+  uint64_t dirs_unit_stride;  // dwords per unit
   uint64_t brow_unit_stride;  // ints per unit
-  uint32_t pairs_per_unit;    // pairs sharing one unit of workspace
-  size_t bytes_per_block;     // workspace bytes per block of kBlock threads
+  uint64_t qpk_unit_words, tpk_unit_words;
+  size_t bytes_per_block;     // workspace bytes per workgroup (4 units)
   uint32_t pairs_per_block;
+  const char* name;
 };
 
-Plan make_plan(uint32_t /*n*/, uint32_t max_q, uint32_t max_t, int /*type*/, int /*match*/,
-               int /*mismatch*/, int /*gap*/) {
+// Can the packed 16-bit lane kernel reproduce this batch exactly?  (Preconditions at the top of
+// align_lane_pk16.h.)  Fills K / bias on success.
+bool lane_pk16_applicable(const sa_align_batch& b, int K, uint32_t* bias_out) {
+  if (K > 64) return false;
+  const long match = b.match, mismatch = b.mismatch, gap = b.gap;
+  if (gap > 0 || mismatch > match || match < gap) return false;
+  const long Q = b.max_qlen, T = b.max_tlen;
+  if (Q == 0 || T == 0) return false;
+  const long t_pad = (T + K - 1) / K * K;
+  long lo, hi, window;
+  if (b.type == SA_LOCAL) {
+    if (gap >= 0 || mismatch >= 0 || match <= 0) return false;
+    lo = std::min(gap, mismatch);
+    hi = match * std::min(Q, t_pad);
+    window = 511;  // the best-cell key keeps 6 bits for the row inside the strip
+  } else {
+    if (b.min_qlen != b.max_qlen || b.min_tlen != b.max_tlen) return false;
+    lo = (b.type == SA_GLOBAL ? gap * (Q + t_pad) : gap * Q) + std::min(gap, std::min(mismatch, 0L));
+    hi = std::max(match, 0L) * std::min(Q, t_pad);
+    window = 0x7FFF;
+  }
+  const long bias = 1 - lo;  // S(x) = x + bias >= 1 for every value formed
+  if (hi + bias + (match - gap) + 1 > window) return false;
+  if (Q >= 0x7FFF || t_pad + 64 >= 0x7FFF) return false;  // packed row/column indices
+  *bias_out = (uint32_t)bias;
+  return true;
+}
+
+int pk16_strip_rows() {
+  static int k = [] {
+    const char* e = getenv("SA_PK16_K");
+    int v = e ? atoi(e) : 48;
+    return (v == 32 || v == 48 || v == 64) ? v : 48;
+  }();
+  return k;
+}
+
+Plan make_plan(const sa_align_batch& b) {
   Plan pl{};
-  pl.family = Family::LaneI32;
-  pl.nstrips = (max_t + kLaneI32K - 1) / kLaneI32K;
-  if (pl.nstrips == 0) pl.nstrips = 1;
-  pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_q ? max_q : 1) * (kLaneI32K / 16) * 64;
-  pl.brow_unit_stride = (uint64_t)(max_q + 1) * 64;
-  pl.pairs_per_unit = 64;
-  pl.pairs_per_block = kBlock;
+  const uint32_t max_q = b.max_qlen ? b.max_qlen : 1, max_t = b.max_tlen ? b.max_tlen : 1;
+  uint32_t bias = 0;
+  const int K16 = pk16_strip_rows();
+  const bool force_i32 = getenv("SA_FORCE_I32") != nullptr;
+  if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
+    pl.family = Family::LanePk16;
+    pl.name = "lane_pk16";
+    pl.K = K16;
+    pl.bias = bias;
+    pl.nstrips = (max_t + K16 - 1) / K16;
+    pl.t_pad = pl.nstrips * K16;
+    const uint32_t ng = (K16 + 15) / 16;
+    pl.pairs_per_unit = 128;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * max_q * ng * 128;
+    pl.brow_unit_stride = (uint64_t)(max_q + 1) * 64;
+    pl.qpk_unit_words = (uint64_t)max_q * 64;
+    pl.tpk_unit_words = (uint64_t)pl.t_pad * 64;
+  } else {
+    pl.family = Family::LaneI32;
+    pl.name = "lane_i32";
+    pl.K = kLaneI32K;
+    pl.nstrips = (max_t + kLaneI32K - 1) / kLaneI32K;
+    pl.t_pad = pl.nstrips * kLaneI32K;
+    pl.pairs_per_unit = 64;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * max_q * (kLaneI32K / 16) * 64;
+    pl.brow_unit_stride = (uint64_t)(max_q + 1) * 64;
+  }
   const size_t units = kBlock / 64;
+  pl.pairs_per_block = (uint32_t)units * pl.pairs_per_unit;
   pl.bytes_per_block = round_up(units * pl.dirs_unit_stride * 4, 256) +
                        round_up(units * pl.brow_unit_stride * 4, 256) +
+                       round_up(units * pl.qpk_unit_words * 4, 256) +
+                       round_up(units * pl.tpk_unit_words * 4, 256) +
                        round_up((size_t)pl.pairs_per_block * 4, 256) * 3;
   return pl;
 }
@@ -83,7 +150,7 @@ struct Timed {
 };
 
 template <int MODE>
-int launch_pass(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
+int launch_lane_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback) {
   const uint32_t blocks = (a.pairs_in_pass + kBlock - 1) / kBlock;
   {
     Timed tm(stream, 1);
@@ -99,8 +166,48 @@ int launch_pass(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool nee
     }
     SA_HIP_TRY(hipGetLastError());
   }
-  (void)pl;
   return SA_OK;
+}
+
+template <int MODE, int K>
+int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
+                     hipStream_t stream, bool need_traceback) {
+  const uint32_t units = (a.pairs_in_pass + 127) / 128;
+  {
+    Timed tm(stream, 0);
+    hipLaunchKernelGGL(pack_lane_pk16, dim3((a.max_q + 63) / 64, units), dim3(256), 0, stream, a.q,
+                       a.q_off, a.pair_base, a.pairs_in_pass, a.max_q, kQueryPad, qpk);
+    hipLaunchKernelGGL(pack_lane_pk16, dim3((pl.t_pad + 63) / 64, units), dim3(256), 0, stream, a.t,
+                       a.t_off, a.pair_base, a.pairs_in_pass, pl.t_pad, kTargetPad, tpk);
+  }
+  SA_HIP_TRY(hipGetLastError());
+  Pk16Args x{qpk, tpk, pl.t_pad, pl.bias, units};
+  {
+    Timed tm(stream, 1);
+    hipLaunchKernelGGL((fill_lane_pk16<MODE, K>), dim3((units + 3) / 4), dim3(kBlock), 0, stream, a, x);
+  }
+  SA_HIP_TRY(hipGetLastError());
+  if (need_traceback) {
+    LanePk16Layout<K> lay{a.dirs, a.dirs_unit_stride, a.max_q};
+    {
+      Timed tm(stream, 2);
+      hipLaunchKernelGGL((traceback_kernel<MODE, LanePk16Layout<K>>),
+                         dim3((a.pairs_in_pass + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a, lay);
+    }
+    SA_HIP_TRY(hipGetLastError());
+  }
+  return SA_OK;
+}
+
+template <int MODE>
+int launch_pass(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk, hipStream_t stream,
+                bool need_tb) {
+  if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
+  switch (pl.K) {
+    case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, stream, need_tb);
+    case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, stream, need_tb);
+    default: return launch_lane_pk16<MODE, 48>(pl, a, qpk, tpk, stream, need_tb);
+  }
 }
 
 }  // namespace
@@ -149,16 +256,17 @@ int sa_align_profile_read(double ms[3], uint64_t launches[3]) {
   return SA_OK;
 }
 
-size_t sa_align_workspace_bytes(uint32_t n, uint32_t max_qlen, uint32_t max_tlen, int type,
-                                size_t* min_bytes) {
-  Plan pl = make_plan(n, max_qlen, max_tlen, type, 1, -1, -1);
-  const size_t blocks = ((size_t)n + pl.pairs_per_block - 1) / pl.pairs_per_block;
+size_t sa_align_workspace_bytes(const sa_align_batch* b, size_t* min_bytes) {
+  if (!b) return 0;
+  Plan pl = make_plan(*b);
+  const size_t blocks = ((size_t)b->n + pl.pairs_per_block - 1) / pl.pairs_per_block;
   if (min_bytes) *min_bytes = pl.bytes_per_block;
   return pl.bytes_per_block * (blocks ? blocks : 1);
 }
 
-const char* sa_align_kernel_name(uint32_t, uint32_t, uint32_t, int, int, int, int) {
-  return "lane_i32";
+const char* sa_align_kernel_name(const sa_align_batch* b) {
+  if (!b) return "";
+  return make_plan(*b).name;
 }
 
 int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, void* d_workspace,
@@ -177,7 +285,7 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   SA_HIP_TRY(hipSetDevice(device));
   hipStream_t stream = (hipStream_t)stream_;
 
-  const Plan pl = make_plan(b->n, b->max_qlen, b->max_tlen, b->type, b->match, b->mismatch, b->gap);
+  const Plan pl = make_plan(*b);
   if (!d_workspace || workspace_bytes < pl.bytes_per_block)
     return fail(SA_ERR_WORKSPACE, "workspace of %zu bytes is below the minimum %zu", workspace_bytes,
                 pl.bytes_per_block);
@@ -194,8 +302,8 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   a.q_off = b->d_q_off;
   a.t = b->d_t;
   a.t_off = b->d_t_off;
-  a.max_q = b->max_qlen;
-  a.max_t = b->max_tlen;
+  a.max_q = b->max_qlen ? b->max_qlen : 1;
+  a.max_t = b->max_tlen ? b->max_tlen : 1;
   a.match = b->match;
   a.mismatch = b->mismatch;
   a.gap = b->gap;
@@ -205,6 +313,10 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   a.brow = (int32_t*)w;
   a.brow_unit_stride = pl.brow_unit_stride;
   w += round_up(units_per_pass * pl.brow_unit_stride * 4, 256);
+  uint32_t* qpk = (uint32_t*)w;
+  w += round_up(units_per_pass * pl.qpk_unit_words * 4, 256);
+  uint32_t* tpk = (uint32_t*)w;
+  w += round_up(units_per_pass * pl.tpk_unit_words * 4, 256);
   a.end_score = (int32_t*)w;
   w += round_up(pairs_per_pass * 4, 256);
   a.end_i = (uint32_t*)w;
@@ -223,11 +335,11 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
     a.pairs_in_pass = (uint32_t)((b->n - base) < pairs_per_pass ? (b->n - base) : pairs_per_pass);
     int rc;
     if (b->type == SA_GLOBAL)
-      rc = launch_pass<SA_GLOBAL>(pl, a, stream, need_tb);
+      rc = launch_pass<SA_GLOBAL>(pl, a, qpk, tpk, stream, need_tb);
     else if (b->type == SA_LOCAL)
-      rc = launch_pass<SA_LOCAL>(pl, a, stream, need_tb);
+      rc = launch_pass<SA_LOCAL>(pl, a, qpk, tpk, stream, need_tb);
     else
-      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, stream, need_tb);
+      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, qpk, tpk, stream, need_tb);
     if (rc) return rc;
   }
   return SA_OK;

@@ -77,6 +77,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // wave's store is one contiguous 256-byte line.
 template <int K>
 struct LaneI32Layout {
+  static constexpr bool kImplicitNone = false;
   const uint32_t* dirs;
   uint64_t wave_stride;
   uint32_t max_q;
@@ -108,21 +109,30 @@ __global__ __launch_bounds__(256) void traceback_kernel(AlignArgs a, Layout lay)
 
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
+  // Layouts that do not store Local's None state: a cell is None exactly when its score is 0
+  // (src/alignment.cpp:190-192 stores {0, None} for max <= 0 and a positive score otherwise), so the
+  // traceback carries the score of the current cell and stops when it reaches 0.
+  int remaining = (MODE == SA_LOCAL && Layout::kImplicitNone) ? a.score[p] : 1;
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
+    if (MODE == SA_LOCAL && Layout::kImplicitNone && remaining == 0) break;
     const uint32_t d = (i == 0 || r == 0) ? border_dir<MODE>(i, r, a.gap) : lay.get(pl, i, r);
     if (d == DIR_NONE) break;
     uint32_t op;
     if (d == DIR_DIAG) {
-      op = (same || t[i - 1] == q[r - 1]) ? SA_OP_M : SA_OP_X;
+      const bool eq = t[i - 1] == q[r - 1];
+      op = (same || eq) ? SA_OP_M : SA_OP_X;
+      if (MODE == SA_LOCAL && Layout::kImplicitNone) remaining -= eq ? a.match : a.mismatch;
       --i;
       --r;
     } else if (d == DIR_LEFT) {
       op = SA_OP_I;
+      if (MODE == SA_LOCAL && Layout::kImplicitNone) remaining -= a.gap;
       --r;
     } else {
       op = SA_OP_D;
+      if (MODE == SA_LOCAL && Layout::kImplicitNone) remaining -= a.gap;
       --i;
     }
     if (op == cur_op) {

@@ -1,0 +1,299 @@
+// Inter-pair batched DP fill for short pairs: TWO pairs per lane (128 pairs per wavefront), scores as
+// packed unsigned 16-bit halves of one VGPR.  Same recurrence, tie-break and clamping as the reference
+// (src/alignment.cpp:63-85, 176-201, 281-303); what differs is only the number representation:
+//
+//   * a score x is held as S(x) = x + BIAS with bit 15 of the half always set (a "guard" bit), so that
+//     plain 32-bit v_add/v_sub on the register act as two independent 16-bit operations (no carry or
+//     borrow ever crosses the halves) and unsigned packed max orders the halves correctly;
+//   * the register strip runs along the TARGET (K rows), the lane's loop along the QUERY;
+//     Hc[k] holds S(H[i][r-1] + gap) of its row, which serves both as the "left" candidate of the next
+//     column and, shifted by (match - gap), as the "diagonal" base of the row below;
+//   * per cell two flags are kept, A = (max == diag candidate) and B = (max == left candidate); they are
+//     bit 15 of (candidate - max) thanks to the guard bit.  Diag > Left > Up follows from reading A
+//     first, then B.  Local's None state is not stored: a cell is None exactly when its score is 0, which
+//     the traceback knows from the running score.
+//   * Local's best cell (first strict maximum in row-major order, src/alignment.cpp:203-207) is tracked
+//     with one packed max per cell on the key (S(H) << 6) | (63 - k): larger score first, then smaller
+//     row inside the strip; strips are visited in increasing row order and columns in increasing order.
+//
+// Preconditions (checked on the host by lane_pk16_applicable): gap <= 0, mismatch <= match,
+// match >= gap, all scores within the 15-bit window; Local additionally gap < 0, mismatch < 0 and a
+// 9-bit score window.  Global/Semiglobal need equal lengths across the batch.
+#ifndef SA_ALIGN_LANE_PK16_H
+#define SA_ALIGN_LANE_PK16_H
+
+#include "align_common.h"
+
+namespace sa {
+
+constexpr uint32_t kGuard2 = 0x80008000u;
+constexpr uint32_t kQueryPad = 0x0100u;   // symbol codes outside the byte range: never equal to a real
+constexpr uint32_t kTargetPad = 0x0200u;  // symbol nor to each other
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// per half: a * b + c (mod 2^16)
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// (mask & a) | (~mask & b)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t rep2(uint32_t v16) { return (v16 & 0xFFFFu) * 0x00010001u; }
+
+// 0x7FFF in every half whose value is non-zero (value < 0x8000), else 0.
+__device__ __forceinline__ uint32_t nonzero_mask15(uint32_t v) {
+  const uint32_t y = (v + 0x7FFF7FFFu) & kGuard2;
+  return y - (y >> 15);
+}
+
+struct Pk16Args {
+  const uint32_t* qpk;  // [unit][max_q][64]  query symbols, pair A in the low half, pair B in the high
+  const uint32_t* tpk;  // [unit][t_pad][64]  target symbols
+  uint32_t t_pad;       // nstrips * K
+  uint32_t bias;        // BIAS
+  uint32_t units;       // waves of 128 pairs in this pass
+};
+
+// Number of direction dwords a lane writes per query column and strip: 2 planes per group of 16 rows.
+template <int K>
+struct LanePk16Geom {
+  static constexpr int NG = (K + 15) / 16;
+  static constexpr int WORDS = 2 * NG;
+};
+
+template <int K>
+struct LanePk16Layout {
+  static constexpr bool kImplicitNone = true;
+  const uint32_t* dirs;
+  uint64_t unit_stride;
+  uint32_t max_q;
+  // -> plane A bit, plane B bit of cell (i, r) of pair `pair_local` of the pass
+  __device__ __forceinline__ void flags(uint32_t pair_local, uint32_t i, uint32_t r, uint32_t& fa,
+                                        uint32_t& fb) const {
+    constexpr int NG = LanePk16Geom<K>::NG;
+    const uint32_t unit = pair_local >> 7, within = pair_local & 127;
+    const uint32_t lane = within & 63, half = within >> 6;
+    const uint32_t s = (i - 1) / K, k = (i - 1) % K;
+    const uint32_t g = k >> 4, j = k & 15;
+    const uint32_t gs = (g == NG - 1) ? (K - 16 * (NG - 1)) : 16;
+    const uint32_t bit = 16 * half + 15 - (gs - 1 - j);
+    const uint64_t w = (((uint64_t)(s * max_q + (r - 1)) * NG + g) * 64 + lane) * 2;
+    const uint2 v = *reinterpret_cast<const uint2*>(dirs + unit * unit_stride + w);
+    fa = (v.x >> bit) & 1u;
+    fb = (v.y >> bit) & 1u;
+  }
+  __device__ __forceinline__ uint32_t get(uint32_t pair_local, uint32_t i, uint32_t r) const {
+    uint32_t fa, fb;
+    flags(pair_local, i, r, fa, fb);
+    return fa ? DIR_DIAG : (fb ? DIR_LEFT : DIR_UP);
+  }
+};
+
+template <int MODE, int K>
+__global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
+  constexpr int NG = LanePk16Geom<K>::NG;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (unit >= x.units) return;  // whole waves only: blockDim is a multiple of 64
+
+  // the two pairs of this lane
+  const uint32_t plA = unit * 128 + lane, plB = plA + 64;
+  const bool actA = plA < a.pairs_in_pass, actB = plB < a.pairs_in_pass;
+  uint32_t QA = 0, TA = 0, QB = 0, TB = 0;
+  if (actA) {
+    const uint32_t p = a.pair_base + plA;
+    QA = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
+    TA = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
+  }
+  if (actB) {
+    const uint32_t p = a.pair_base + plB;
+    QB = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
+    TB = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
+  }
+  const uint32_t maxQ = wave_max_u32(QA > QB ? QA : QB);
+  const uint32_t maxT = wave_max_u32(TA > TB ? TA : TB);
+  const uint32_t nstrips = (maxT + K - 1) / K;
+
+  const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
+  const uint32_t* tpk = x.tpk + (uint64_t)unit * x.t_pad * 64 + lane;
+  uint32_t* brow = reinterpret_cast<uint32_t*>(a.brow) + (uint64_t)unit * a.brow_unit_stride + lane;
+  uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride + (uint64_t)lane * 2;
+
+  const int gap = a.gap;
+  const uint32_t G = kGuard2;
+  const uint32_t bias = x.bias;
+  const uint32_t gsub2 = rep2((uint32_t)(-gap));                 // |gap| in both halves (gap <= 0)
+  const uint32_t mg2 = rep2((uint32_t)(a.match - gap));          // match - gap >= 0
+  const uint32_t negdelta2 = rep2((uint32_t)(a.mismatch - a.match));  // per half, mod 2^16
+  const uint32_t one2 = 0x00010001u;
+  const uint32_t floorG = rep2(bias) | G;                        // S(0)
+
+  // S(x) with guard for a small signed x
+  auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v)) | G; };
+
+  uint32_t best = (rep2(bias) << 6) | 0x003F003Fu;  // Local: key of "score 0", never beaten by a 0 cell
+  uint32_t bi2 = 0, br2 = 0;                        // packed rows / columns of the best cells
+  uint32_t sgbest = SG(gap);                        // Semiglobal: S(0 + gap), compared with Hc values
+  uint32_t sgrow2 = 0;
+  uint32_t final2 = 0;
+
+  for (uint32_t s = 0; s < nstrips; ++s) {
+    const uint32_t i0 = s * K;
+    uint32_t Tk[K], Hc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      Tk[k] = tpk[(uint64_t)(i0 + k) * 64];
+      // column 0: S(H[i][0] + gap)
+      Hc[k] = SG(border_col0<MODE>((int)(i0 + 1 + k), gap) + gap);
+    }
+    // S(H[i0][0] + gap): base of the diagonal of row i0+1 at column 1
+    uint32_t top_prev = SG(((i0 == 0) ? 0 : border_col0<MODE>((int)i0, gap)) + gap);
+    const uint32_t best_strip0 = best;
+    uint32_t qq = qpk[0];
+    for (uint32_t r = 1; r <= maxQ; ++r) {
+      const uint32_t qcur = qq;
+      if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch next column's symbols
+      const uint32_t top =
+          (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap) : brow[(uint64_t)r * 64];
+      uint32_t diag = top_prev, up = top;
+      const uint32_t best_before = best;
+      uint32_t accA = 0, accB = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint32_t left = Hc[k];                         // S(H[i][r-1] + gap)
+        const uint32_t ne = pk_min_u16(Tk[k] ^ qcur, one2);  // 1 where the symbols differ
+        const uint32_t dG = pk_mad_u16(ne, negdelta2, diag + mg2);  // S(H[i-1][r-1] + sub)
+        uint32_t mG = pk_max_u16(dG, up);
+        if (MODE == SA_LOCAL)
+          mG = pk_max_u16(mG, pk_max_u16(left, floorG));
+        else
+          mG = pk_max_u16(mG, left);
+        const uint32_t m = mG ^ G;
+        accA = bfi(G, dG - m, accA >> 1);    // bit 15 of (candidate - max) == (candidate == max)
+        accB = bfi(G, left - m, accB >> 1);
+        if (MODE == SA_LOCAL) best = pk_max_u16(best, (m << 6) | rep2(63 - k));
+        const uint32_t hg = mG - gsub2;  // S(H[i][r] + gap)
+        diag = left;
+        Hc[k] = hg;
+        up = hg;
+        if ((k & 15) == 15 || k == K - 1) {
+          *reinterpret_cast<uint2*>(dirs + ((uint64_t)(s * a.max_q + (r - 1)) * NG + (k >> 4)) * 128) =
+              make_uint2(accA, accB);
+          accA = 0;
+          accB = 0;
+        }
+      }
+      if (s + 1 < nstrips) brow[(uint64_t)r * 64] = up;
+      top_prev = top;
+      if (MODE == SA_LOCAL) {
+        const uint32_t ch = nonzero_mask15(best ^ best_before);
+        br2 = bfi(ch, rep2(r), br2);
+      }
+    }
+    if (MODE == SA_LOCAL) {
+      const uint32_t ch = nonzero_mask15(best ^ best_strip0);
+      const uint32_t rows = rep2(i0 + 64) - (best & 0x003F003Fu);  // i0 + 1 + k, k = 63 - low bits
+      bi2 = bfi(ch, rows, bi2);
+      best |= 0x003F003Fu;  // a later strip (larger rows) wins only with a strictly larger score
+    } else if (MODE == SA_SEMIGLOBAL) {
+      // column Q (= maxQ for the equal-length batches this kernel accepts): first strict maximum > 0
+      // over rows in increasing order (src/alignment.cpp:87-92); Hc holds S(H[i][Q] + gap).
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint32_t i = i0 + 1 + k;
+        const uint32_t nb = pk_max_u16(sgbest, Hc[k]);
+        uint32_t ch = nonzero_mask15(nb ^ sgbest);
+        // rows beyond the pair's target are padding
+        if (i > TA) ch &= 0xFFFF0000u;
+        if (i > TB) ch &= 0x0000FFFFu;
+        sgbest = bfi(ch, nb, sgbest);
+        sgrow2 = bfi(ch, rep2(i), sgrow2);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint32_t i = i0 + 1 + k;
+        if (i == TA) final2 = (final2 & 0xFFFF0000u) | (Hc[k] & 0x0000FFFFu);
+        if (i == TB) final2 = (final2 & 0x0000FFFFu) | (Hc[k] & 0xFFFF0000u);
+      }
+    }
+  }
+
+  // unpack the two pairs' results
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const bool act = h ? actB : actA;
+    if (!act) continue;
+    const uint32_t pl = h ? plB : plA;
+    const uint32_t Q = h ? QB : QA, T = h ? TB : TA;
+    const uint32_t p = a.pair_base + pl;
+    const uint32_t sh = 16 * h;
+    int score;
+    uint32_t ei, er;
+    if (MODE == SA_LOCAL) {
+      score = (int)(((best >> sh) & 0xFFFFu) >> 6) - (int)bias;
+      ei = (bi2 >> sh) & 0xFFFFu;
+      er = (br2 >> sh) & 0xFFFFu;
+    } else if (MODE == SA_SEMIGLOBAL) {
+      ei = (sgrow2 >> sh) & 0xFFFFu;
+      er = Q;
+      score = ei ? (int)((sgbest >> sh) & 0x7FFFu) - (int)bias - gap : border_row0<MODE>((int)Q, gap);
+    } else {
+      ei = T;
+      er = Q;
+      if (Q == 0 || T == 0)
+        score = (T == 0) ? border_row0<MODE>((int)Q, gap) : border_col0<MODE>((int)T, gap);
+      else
+        score = (int)((final2 >> sh) & 0x7FFFu) - (int)bias - gap;
+    }
+    a.score[p] = score;
+    a.end_i[pl] = ei;
+    a.end_r[pl] = er;
+  }
+}
+
+// Transposes the byte sequences of a pass into the lane-interleaved layout the fill kernel reads:
+// out[unit][pos][lane] = symbol of pair (unit*128 + lane) | symbol of pair (unit*128 + 64 + lane) << 16,
+// with `pad` beyond the end of a sequence.  One workgroup per (unit, tile of 64 positions).
+__global__ __launch_bounds__(256) void pack_lane_pk16(const uint8_t* seq, const uint64_t* off,
+                                                      uint32_t pair_base, uint32_t pairs_in_pass,
+                                                      uint32_t len_cap, uint32_t pad, uint32_t* out) {
+  __shared__ uint16_t tile[128][66];
+  const uint32_t unit = blockIdx.y, t0 = blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t pp = wv; pp < 128; pp += 4) {
+    const uint32_t pl = unit * 128 + pp;
+    uint16_t v = (uint16_t)pad;
+    if (pl < pairs_in_pass) {
+      const uint64_t b = off[pair_base + pl], e = off[pair_base + pl + 1];
+      const uint64_t pos = b + t0 + lane;
+      if (pos < e) v = seq[pos];
+    }
+    tile[pp][lane] = v;
+  }
+  __syncthreads();
+  for (uint32_t c = wv; c < 64; c += 4) {
+    const uint32_t pos = t0 + c;
+    if (pos < len_cap)
+      out[((uint64_t)unit * len_cap + pos) * 64 + lane] =
+          (uint32_t)tile[lane][c] | ((uint32_t)tile[lane + 64][c] << 16);
+  }
+}
+
+}  // namespace sa
+
+#endif

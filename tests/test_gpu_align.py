@@ -114,9 +114,7 @@ def test_small_workspace_multiple_passes(oracle):
     import ctypes as C
     from sequencealigner_amd import align, capi, synth
     q, t = synth.pairs_short_read_window(700, seed=8, read_len=60, window_len=90)
-    mb = C.c_size_t(0)
-    capi.lib().sa_align_workspace_bytes(700, 60, 90, 1, C.byref(mb))
-    b = align.DeviceAlignBatch(q, t, 1, 1, -1, -1, workspace_bytes=mb.value)
+    b = align.DeviceAlignBatch(q, t, 1, 1, -1, -1, workspace_bytes=1)  # clamped to the minimum
     b.run()
     import torch
     torch.cuda.synchronize()
