@@ -98,7 +98,7 @@ Plan make_plan(const sa_align_batch& b) {
     pl.t_pad = pl.nstrips * K16;
     const uint32_t ng = (K16 + 15) / 16;
     pl.pairs_per_unit = 128;
-    pl.dirs_unit_stride = (uint64_t)pl.nstrips * max_q * ng * 128;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * ((max_q + kColBlock - 1) / kColBlock) * ng * 1024;
     pl.brow_unit_stride = (uint64_t)(max_q + 1) * 64;
     pl.qpk_unit_words = (uint64_t)max_q * 64;
     pl.tpk_unit_words = (uint64_t)pl.t_pad * 64;
@@ -188,11 +188,10 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
   }
   SA_HIP_TRY(hipGetLastError());
   if (need_traceback) {
-    LanePk16Layout<K> lay{a.dirs, a.dirs_unit_stride, a.max_q};
     {
       Timed tm(stream, 2);
-      hipLaunchKernelGGL((traceback_kernel<MODE, LanePk16Layout<K>>),
-                         dim3((a.pairs_in_pass + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a, lay);
+      hipLaunchKernelGGL((traceback_lane_pk16<MODE, K>), dim3((a.pairs_in_pass + kBlock - 1) / kBlock),
+                         dim3(kBlock), 0, stream, a);
     }
     SA_HIP_TRY(hipGetLastError());
   }

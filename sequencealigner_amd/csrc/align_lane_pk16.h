@@ -75,40 +75,32 @@ struct LanePk16Geom {
   static constexpr int WORDS = 2 * NG;
 };
 
+// Direction storage of the packed lane kernel.  Per strip s, per block of 8 query columns rb and per
+// group g of 16 target rows, the 64 lanes of a wave own one 4 KiB tile:
+//     dword[((s * nrb + rb) * NG + g) * 1024 + lane * 16 + (column % 8) * 2 + plane]
+// i.e. every lane (two pairs) has its 8 columns x 2 planes contiguous in one 64-byte segment, which is
+// what the traceback fetches: a diagonal path stays ~8 steps inside one segment.  The fill kernel
+// stages the words of 8 columns in LDS and writes each tile with fully coalesced 1 KiB stores.
+constexpr int kColBlock = 8;
+
 template <int K>
-struct LanePk16Layout {
-  static constexpr bool kImplicitNone = true;
-  const uint32_t* dirs;
-  uint64_t unit_stride;
-  uint32_t max_q;
-  // -> plane A bit, plane B bit of cell (i, r) of pair `pair_local` of the pass
-  __device__ __forceinline__ void flags(uint32_t pair_local, uint32_t i, uint32_t r, uint32_t& fa,
-                                        uint32_t& fb) const {
-    constexpr int NG = LanePk16Geom<K>::NG;
-    const uint32_t unit = pair_local >> 7, within = pair_local & 127;
-    const uint32_t lane = within & 63, half = within >> 6;
-    const uint32_t s = (i - 1) / K, k = (i - 1) % K;
-    const uint32_t g = k >> 4, j = k & 15;
-    const uint32_t gs = (g == NG - 1) ? (K - 16 * (NG - 1)) : 16;
-    const uint32_t bit = 16 * half + 15 - (gs - 1 - j);
-    const uint64_t w = (((uint64_t)(s * max_q + (r - 1)) * NG + g) * 64 + lane) * 2;
-    const uint2 v = *reinterpret_cast<const uint2*>(dirs + unit * unit_stride + w);
-    fa = (v.x >> bit) & 1u;
-    fb = (v.y >> bit) & 1u;
-  }
-  __device__ __forceinline__ uint32_t get(uint32_t pair_local, uint32_t i, uint32_t r) const {
-    uint32_t fa, fb;
-    flags(pair_local, i, r, fa, fb);
-    return fa ? DIR_DIAG : (fb ? DIR_LEFT : DIR_UP);
+struct LanePk16Tiles {
+  static constexpr int NG = LanePk16Geom<K>::NG;
+  __host__ __device__ static uint32_t col_blocks(uint32_t max_q) { return (max_q + kColBlock - 1) / kColBlock; }
+  __host__ __device__ static uint64_t unit_dwords(uint32_t nstrips, uint32_t max_q) {
+    return (uint64_t)nstrips * col_blocks(max_q) * NG * 1024;
   }
 };
 
 template <int MODE, int K>
 __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   constexpr int NG = LanePk16Geom<K>::NG;
+  // per wave: NG groups x 8 columns x 64 lanes of (plane A, plane B) words awaiting the tile store
+  __shared__ uint2 stage_all[4][NG * kColBlock * 64];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (unit >= x.units) return;  // whole waves only: blockDim is a multiple of 64
+  uint2* stage = stage_all[threadIdx.x >> 6];
 
   // the two pairs of this lane
   const uint32_t plA = unit * 128 + lane, plB = plA + 64;
@@ -131,7 +123,27 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
   const uint32_t* tpk = x.tpk + (uint64_t)unit * x.t_pad * 64 + lane;
   uint32_t* brow = reinterpret_cast<uint32_t*>(a.brow) + (uint64_t)unit * a.brow_unit_stride + lane;
-  uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride + (uint64_t)lane * 2;
+  uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride;
+  const uint32_t nrb = LanePk16Tiles<K>::col_blocks(a.max_q);
+  // Writes the staged words of column block rb of strip s as NG tiles of 4 KiB.  Lane L stores 16
+  // bytes at tile offset c*1024 + L*16: segment (16c + L/4), columns 2*(L%4) and 2*(L%4)+1.
+  auto flush_tiles = [&](uint32_t s, uint32_t rb) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      uint32_t* tile = dirs + ((uint64_t)(s * nrb + rb) * NG + g) * 1024;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t seg = 16 * c + (lane >> 2), col = 2 * (lane & 3);
+        const uint2 w0 = stage[(g * kColBlock + col) * 64 + seg];
+        const uint2 w1 = stage[(g * kColBlock + col + 1) * 64 + seg];
+        *reinterpret_cast<uint4*>(tile + c * 256 + lane * 4) = make_uint4(w0.x, w0.y, w1.x, w1.y);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
 
   const int gap = a.gap;
   const uint32_t G = kGuard2;
@@ -191,12 +203,12 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
         Hc[k] = hg;
         up = hg;
         if ((k & 15) == 15 || k == K - 1) {
-          *reinterpret_cast<uint2*>(dirs + ((uint64_t)(s * a.max_q + (r - 1)) * NG + (k >> 4)) * 128) =
-              make_uint2(accA, accB);
+          stage[((k >> 4) * kColBlock + ((r - 1) & (kColBlock - 1))) * 64 + lane] = make_uint2(accA, accB);
           accA = 0;
           accB = 0;
         }
       }
+      if (((r - 1) & (kColBlock - 1)) == kColBlock - 1 || r == maxQ) flush_tiles(s, (r - 1) / kColBlock);
       if (s + 1 < nstrips) brow[(uint64_t)r * 64] = up;
       top_prev = top;
       if (MODE == SA_LOCAL) {
@@ -263,6 +275,111 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
     a.score[p] = score;
     a.end_i[pl] = ei;
     a.end_r[pl] = er;
+  }
+}
+
+// Traceback + run-length encoding for the tiled layout above, one pair per thread; same rules as
+// traceback_kernel (align_common.h).  The thread keeps the current 64-byte direction segment and 8
+// symbols of each sequence in registers, so a path of ~(Q+T) steps costs ~(Q+T)/8 memory round trips.
+template <int MODE, int K>
+__global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
+  constexpr int NG = LanePk16Geom<K>::NG;
+  const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= a.pairs_in_pass) return;
+  const uint32_t p = a.pair_base + pl;
+  const uint64_t qb = a.q_off[p], tb0 = a.t_off[p];
+  const uint32_t Q = (uint32_t)(a.q_off[p + 1] - qb);
+  const uint32_t T = (uint32_t)(a.t_off[p + 1] - tb0);
+  uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
+  uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
+  const bool same = (a.match == a.mismatch);
+  const uint32_t unit = pl >> 7, lane = pl & 63, half = (pl >> 6) & 1;
+  const uint32_t nrb = LanePk16Tiles<K>::col_blocks(a.max_q);
+  const uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride + lane * 16;
+
+  uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
+  uint32_t nruns = 0, cur_op = 4, cur_len = 0;
+  int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
+
+  uint32_t cached_tile = 0xFFFFFFFFu;
+  uint4 seg0 = make_uint4(0, 0, 0, 0), seg1 = seg0, seg2 = seg0, seg3 = seg0;
+  // 8-symbol windows of the sequences: bytes [base, base + 8) of the blob, base 8-byte aligned
+  uint64_t qwin_base = ~0ull, twin_base = ~0ull;
+  uint64_t qwin = 0, twin = 0;
+
+  for (;;) {
+    if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
+    if (MODE == SA_SEMIGLOBAL && r == 0) break;
+    if (MODE == SA_LOCAL && remaining == 0) break;
+    uint32_t d;
+    if (i == 0 || r == 0) {
+      d = border_dir<MODE>(i, r, a.gap);
+    } else {
+      const uint32_t s = (i - 1) / K, k = (i - 1) % K;
+      const uint32_t g = k >> 4, j = k & 15;
+      const uint32_t gs = (g == NG - 1) ? (K - 16 * (NG - 1)) : 16;
+      const uint32_t bit = 16 * half + 15 - (gs - 1 - j);
+      const uint32_t tile = (s * nrb + (r - 1) / kColBlock) * NG + g;
+      if (tile != cached_tile) {
+        const uint4* src = reinterpret_cast<const uint4*>(dirs + (uint64_t)tile * 1024);
+        seg0 = src[0];
+        seg1 = src[1];
+        seg2 = src[2];
+        seg3 = src[3];
+        cached_tile = tile;
+      }
+      const uint32_t c = (r - 1) & (kColBlock - 1);
+      const uint4 sel = (c < 4) ? ((c < 2) ? seg0 : seg1) : ((c < 6) ? seg2 : seg3);
+      const uint32_t wa = (c & 1) ? sel.z : sel.x, wb = (c & 1) ? sel.w : sel.y;
+      d = ((wa >> bit) & 1u) ? DIR_DIAG : (((wb >> bit) & 1u) ? DIR_LEFT : DIR_UP);
+    }
+    if (d == DIR_NONE) break;
+    uint32_t op;
+    if (d == DIR_DIAG) {
+      const uint64_t qa = qb + (r - 1), ta = tb0 + (i - 1);
+      if ((qa & ~7ull) != qwin_base) {
+        qwin_base = qa & ~7ull;
+        qwin = *reinterpret_cast<const uint64_t*>(a.q + qwin_base);
+      }
+      if ((ta & ~7ull) != twin_base) {
+        twin_base = ta & ~7ull;
+        twin = *reinterpret_cast<const uint64_t*>(a.t + twin_base);
+      }
+      const bool eq = ((qwin >> (8 * (qa & 7))) & 0xFF) == ((twin >> (8 * (ta & 7))) & 0xFF);
+      op = (same || eq) ? SA_OP_M : SA_OP_X;
+      if (MODE == SA_LOCAL) remaining -= eq ? a.match : a.mismatch;
+      --i;
+      --r;
+    } else if (d == DIR_LEFT) {
+      op = SA_OP_I;
+      if (MODE == SA_LOCAL) remaining -= a.gap;
+      --r;
+    } else {
+      op = SA_OP_D;
+      if (MODE == SA_LOCAL) remaining -= a.gap;
+      --i;
+    }
+    if (op == cur_op) {
+      ++cur_len;
+    } else {
+      if (cur_len) {
+        ++nruns;
+        if (slot_end) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
+      }
+      cur_op = op;
+      cur_len = 1;
+    }
+  }
+  if (cur_len) {
+    ++nruns;
+    if (slot_end) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
+  }
+  if (a.cigar_nruns) a.cigar_nruns[p] = nruns;
+  if (a.target_begin) {
+    if (MODE == SA_LOCAL)
+      a.target_begin[p] = i;
+    else
+      a.target_begin[p] = (cur_len && cur_op == SA_OP_D && cur_len <= 9) ? 3u : 1u;
   }
 }
 
