@@ -92,9 +92,153 @@ struct LanePk16Tiles {
   }
 };
 
+// Per-lane state of the fill that outlives a strip.
+struct LanePk16State {
+  uint32_t best;     // Local: packed keys S(best score) | (63 - row in strip), guard bit set
+  uint32_t bi2, br2; // Local: packed row / column of the best cells
+  uint32_t sgbest;   // Semiglobal: packed S(best last-column score + gap), guard bit set
+  uint32_t sgrow2;   // Semiglobal: packed rows of those
+  uint32_t final2;   // Global: packed S(H[T][Q] + gap)
+};
+
+// One strip of KS target rows (rows i0+1 .. i0+KS) over all query columns.  KMAX (>= KS) is the
+// strip height the direction tiles and the LDS staging area are laid out for.  SH is the left shift
+// applied to every score (6 for Local, where the low 6 bits of the best-cell key hold the row).
+template <int MODE, int KS, int KMAX, int SH>
+__device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Args& x, uint32_t s,
+                                                uint32_t nstrips, uint32_t maxQ, uint32_t lane,
+                                                const uint32_t* qpk, const uint32_t* tpk, uint32_t* brow,
+                                                uint32_t* dirs, uint2* stage, uint32_t TA, uint32_t TB,
+                                                LanePk16State& st) {
+  constexpr int NG = LanePk16Geom<KMAX>::NG;
+  constexpr int NGS = LanePk16Geom<KS>::NG;
+  const int gap = a.gap;
+  const uint32_t G = kGuard2;
+  const uint32_t bias = x.bias;
+  const uint32_t gsub2 = rep2((uint32_t)(-gap) << SH);                       // |gap|, gap <= 0
+  const uint32_t mg2 = rep2((uint32_t)(a.match - gap) << SH);                // match - gap >= 0
+  const uint32_t negdelta2 = rep2((uint32_t)((a.mismatch - a.match) * (1 << SH)));  // mod 2^16
+  const uint32_t one2 = 0x00010001u;
+  const uint32_t floorG = rep2(bias << SH) | G;  // S(0)
+  auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v) << SH) | G; };
+  const uint32_t nrb = LanePk16Tiles<KMAX>::col_blocks(a.max_q);
+  const uint32_t i0 = s * KMAX;
+
+  // Writes the staged words of column block rb as NGS tiles of 4 KiB.  Lane L stores 16 bytes at tile
+  // offset c*1024 + L*16: segment (16c + L/4), columns 2*(L%4) and 2*(L%4)+1.
+  auto flush_tiles = [&](uint32_t rb) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < NGS; ++g) {
+      uint32_t* tile = dirs + ((uint64_t)(s * nrb + rb) * NG + g) * 1024;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t seg = 16 * c + (lane >> 2), col = 2 * (lane & 3);
+        const uint2 w0 = stage[(g * kColBlock + col) * 64 + seg];
+        const uint2 w1 = stage[(g * kColBlock + col + 1) * 64 + seg];
+        *reinterpret_cast<uint4*>(tile + c * 256 + lane * 4) = make_uint4(w0.x, w0.y, w1.x, w1.y);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  uint32_t Tk[KS], Hc[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    Tk[k] = tpk[(uint64_t)(i0 + k) * 64];
+    Hc[k] = SG(border_col0<MODE>((int)(i0 + 1 + k), gap) + gap);  // column 0: S(H[i][0] + gap)
+  }
+  // S(H[i0][0] + gap): base of the diagonal of row i0+1 at column 1
+  uint32_t top_prev = SG(((i0 == 0) ? 0 : border_col0<MODE>((int)i0, gap)) + gap);
+  const uint32_t best_strip0 = st.best;
+  uint32_t best = st.best;
+  uint32_t qq = qpk[0];
+  for (uint32_t r = 1; r <= maxQ; ++r) {
+    const uint32_t qcur = qq;
+    if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch the next column's symbols
+    const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap) : brow[(uint64_t)r * 64];
+    uint32_t dsrc = top_prev, up = top;
+    const uint32_t best_before = best;
+#pragma unroll
+    for (int c0 = 0; c0 < KS; c0 += 16) {
+      constexpr int CHMAX = 16;
+      // pass 1 (no dependencies between cells): diagonal candidates S(H[i-1][r-1] + sub) of the chunk,
+      // from the previous column's values still held in Hc
+      uint32_t dG[CHMAX];
+#pragma unroll
+      for (int j = 0; j < CHMAX; ++j) {
+        const int k = c0 + j;
+        if (k >= KS) break;
+        const uint32_t base = (j == 0) ? dsrc : Hc[k - 1];
+        const uint32_t ne = pk_min_u16(Tk[k] ^ qcur, one2);  // 1 where the symbols differ
+        dG[j] = pk_mad_u16(ne, negdelta2, base + mg2);
+      }
+      // previous column's value of the chunk's last row, for the next chunk
+      dsrc = Hc[(c0 + CHMAX < KS ? c0 + CHMAX : KS) - 1];
+      // pass 2: the dependent chain down the column
+      uint32_t accA = 0, accB = 0;
+#pragma unroll
+      for (int j = 0; j < CHMAX; ++j) {
+        const int k = c0 + j;
+        if (k >= KS) break;
+        const uint32_t left = Hc[k];  // S(H[i][r-1] + gap)
+        uint32_t mG = pk_max_u16(dG[j], up);
+        if (MODE == SA_LOCAL)
+          mG = pk_max_u16(mG, pk_max_u16(left, floorG));
+        else
+          mG = pk_max_u16(mG, left);
+        const uint32_t m = mG ^ G;
+        accA = bfi(G, dG[j] - m, accA >> 1);  // bit 15 of (candidate - max) == (candidate == max)
+        accB = bfi(G, left - m, accB >> 1);
+        if (MODE == SA_LOCAL) best = pk_max_u16(best, mG | rep2(63 - k));
+        const uint32_t hg = mG - gsub2;  // S(H[i][r] + gap)
+        Hc[k] = hg;
+        up = hg;
+      }
+      stage[((c0 >> 4) * kColBlock + ((r - 1) & (kColBlock - 1))) * 64 + lane] = make_uint2(accA, accB);
+    }
+    if (((r - 1) & (kColBlock - 1)) == kColBlock - 1 || r == maxQ) flush_tiles((r - 1) / kColBlock);
+    if (s + 1 < nstrips) brow[(uint64_t)r * 64] = up;
+    top_prev = top;
+    if (MODE == SA_LOCAL) {
+      const uint32_t ch = nonzero_mask15(best ^ best_before);
+      st.br2 = bfi(ch, rep2(r), st.br2);
+    }
+  }
+  if (MODE == SA_LOCAL) {
+    const uint32_t ch = nonzero_mask15(best ^ best_strip0);
+    const uint32_t rows = rep2(i0 + 64) - (best & 0x003F003Fu);  // i0 + 1 + k, k = 63 - low bits
+    st.bi2 = bfi(ch, rows, st.bi2);
+    st.best = best | 0x003F003Fu;  // a later strip (larger rows) wins only with a strictly larger score
+  } else if (MODE == SA_SEMIGLOBAL) {
+    // column Q (= maxQ for the equal-length batches this kernel accepts): first strict maximum > 0 over
+    // rows in increasing order (src/alignment.cpp:87-92); Hc holds S(H[i][Q] + gap).
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const uint32_t i = i0 + 1 + k;
+      const uint32_t nb = pk_max_u16(st.sgbest, Hc[k]);
+      uint32_t ch = nonzero_mask15(nb ^ st.sgbest);
+      if (i > TA) ch &= 0xFFFF0000u;  // rows beyond the pair's target are padding
+      if (i > TB) ch &= 0x0000FFFFu;
+      st.sgbest = bfi(ch, nb, st.sgbest);
+      st.sgrow2 = bfi(ch, rep2(i), st.sgrow2);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const uint32_t i = i0 + 1 + k;
+      if (i == TA) st.final2 = (st.final2 & 0xFFFF0000u) | (Hc[k] & 0x0000FFFFu);
+      if (i == TB) st.final2 = (st.final2 & 0x0000FFFFu) | (Hc[k] & 0xFFFF0000u);
+    }
+  }
+}
+
 template <int MODE, int K>
 __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   constexpr int NG = LanePk16Geom<K>::NG;
+  constexpr int SH = (MODE == SA_LOCAL) ? 6 : 0;
   // per wave: NG groups x 8 columns x 64 lanes of (plane A, plane B) words awaiting the tile store
   __shared__ uint2 stage_all[4][NG * kColBlock * 64];
   const uint32_t lane = threadIdx.x & 63;
@@ -118,131 +262,35 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   }
   const uint32_t maxQ = wave_max_u32(QA > QB ? QA : QB);
   const uint32_t maxT = wave_max_u32(TA > TB ? TA : TB);
-  const uint32_t nstrips = (maxT + K - 1) / K;
+  // full strips of K rows, then one strip of 16/32/48 rows covering the remainder
+  const uint32_t nfull = maxT / K, rem = maxT - nfull * K;
+  const uint32_t nstrips = nfull + (rem ? 1 : 0);
 
   const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
   const uint32_t* tpk = x.tpk + (uint64_t)unit * x.t_pad * 64 + lane;
   uint32_t* brow = reinterpret_cast<uint32_t*>(a.brow) + (uint64_t)unit * a.brow_unit_stride + lane;
   uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride;
-  const uint32_t nrb = LanePk16Tiles<K>::col_blocks(a.max_q);
-  // Writes the staged words of column block rb of strip s as NG tiles of 4 KiB.  Lane L stores 16
-  // bytes at tile offset c*1024 + L*16: segment (16c + L/4), columns 2*(L%4) and 2*(L%4)+1.
-  auto flush_tiles = [&](uint32_t s, uint32_t rb) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      uint32_t* tile = dirs + ((uint64_t)(s * nrb + rb) * NG + g) * 1024;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t seg = 16 * c + (lane >> 2), col = 2 * (lane & 3);
-        const uint2 w0 = stage[(g * kColBlock + col) * 64 + seg];
-        const uint2 w1 = stage[(g * kColBlock + col + 1) * 64 + seg];
-        *reinterpret_cast<uint4*>(tile + c * 256 + lane * 4) = make_uint4(w0.x, w0.y, w1.x, w1.y);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
 
   const int gap = a.gap;
-  const uint32_t G = kGuard2;
   const uint32_t bias = x.bias;
-  const uint32_t gsub2 = rep2((uint32_t)(-gap));                 // |gap| in both halves (gap <= 0)
-  const uint32_t mg2 = rep2((uint32_t)(a.match - gap));          // match - gap >= 0
-  const uint32_t negdelta2 = rep2((uint32_t)(a.mismatch - a.match));  // per half, mod 2^16
-  const uint32_t one2 = 0x00010001u;
-  const uint32_t floorG = rep2(bias) | G;                        // S(0)
+  LanePk16State st;
+  st.best = (rep2(bias << SH) | kGuard2) | 0x003F003Fu;  // key of "score 0": no 0 cell beats it
+  st.bi2 = st.br2 = 0;
+  st.sgbest = rep2((uint32_t)((int)bias + gap)) | kGuard2;  // S(0 + gap), compared with Hc values
+  st.sgrow2 = 0;
+  st.final2 = 0;
 
-  // S(x) with guard for a small signed x
-  auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v)) | G; };
-
-  uint32_t best = (rep2(bias) << 6) | 0x003F003Fu;  // Local: key of "score 0", never beaten by a 0 cell
-  uint32_t bi2 = 0, br2 = 0;                        // packed rows / columns of the best cells
-  uint32_t sgbest = SG(gap);                        // Semiglobal: S(0 + gap), compared with Hc values
-  uint32_t sgrow2 = 0;
-  uint32_t final2 = 0;
-
-  for (uint32_t s = 0; s < nstrips; ++s) {
-    const uint32_t i0 = s * K;
-    uint32_t Tk[K], Hc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      Tk[k] = tpk[(uint64_t)(i0 + k) * 64];
-      // column 0: S(H[i][0] + gap)
-      Hc[k] = SG(border_col0<MODE>((int)(i0 + 1 + k), gap) + gap);
-    }
-    // S(H[i0][0] + gap): base of the diagonal of row i0+1 at column 1
-    uint32_t top_prev = SG(((i0 == 0) ? 0 : border_col0<MODE>((int)i0, gap)) + gap);
-    const uint32_t best_strip0 = best;
-    uint32_t qq = qpk[0];
-    for (uint32_t r = 1; r <= maxQ; ++r) {
-      const uint32_t qcur = qq;
-      if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch next column's symbols
-      const uint32_t top =
-          (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap) : brow[(uint64_t)r * 64];
-      uint32_t diag = top_prev, up = top;
-      const uint32_t best_before = best;
-      uint32_t accA = 0, accB = 0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint32_t left = Hc[k];                         // S(H[i][r-1] + gap)
-        const uint32_t ne = pk_min_u16(Tk[k] ^ qcur, one2);  // 1 where the symbols differ
-        const uint32_t dG = pk_mad_u16(ne, negdelta2, diag + mg2);  // S(H[i-1][r-1] + sub)
-        uint32_t mG = pk_max_u16(dG, up);
-        if (MODE == SA_LOCAL)
-          mG = pk_max_u16(mG, pk_max_u16(left, floorG));
-        else
-          mG = pk_max_u16(mG, left);
-        const uint32_t m = mG ^ G;
-        accA = bfi(G, dG - m, accA >> 1);    // bit 15 of (candidate - max) == (candidate == max)
-        accB = bfi(G, left - m, accB >> 1);
-        if (MODE == SA_LOCAL) best = pk_max_u16(best, (m << 6) | rep2(63 - k));
-        const uint32_t hg = mG - gsub2;  // S(H[i][r] + gap)
-        diag = left;
-        Hc[k] = hg;
-        up = hg;
-        if ((k & 15) == 15 || k == K - 1) {
-          stage[((k >> 4) * kColBlock + ((r - 1) & (kColBlock - 1))) * 64 + lane] = make_uint2(accA, accB);
-          accA = 0;
-          accB = 0;
-        }
-      }
-      if (((r - 1) & (kColBlock - 1)) == kColBlock - 1 || r == maxQ) flush_tiles(s, (r - 1) / kColBlock);
-      if (s + 1 < nstrips) brow[(uint64_t)r * 64] = up;
-      top_prev = top;
-      if (MODE == SA_LOCAL) {
-        const uint32_t ch = nonzero_mask15(best ^ best_before);
-        br2 = bfi(ch, rep2(r), br2);
-      }
-    }
-    if (MODE == SA_LOCAL) {
-      const uint32_t ch = nonzero_mask15(best ^ best_strip0);
-      const uint32_t rows = rep2(i0 + 64) - (best & 0x003F003Fu);  // i0 + 1 + k, k = 63 - low bits
-      bi2 = bfi(ch, rows, bi2);
-      best |= 0x003F003Fu;  // a later strip (larger rows) wins only with a strictly larger score
-    } else if (MODE == SA_SEMIGLOBAL) {
-      // column Q (= maxQ for the equal-length batches this kernel accepts): first strict maximum > 0
-      // over rows in increasing order (src/alignment.cpp:87-92); Hc holds S(H[i][Q] + gap).
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint32_t i = i0 + 1 + k;
-        const uint32_t nb = pk_max_u16(sgbest, Hc[k]);
-        uint32_t ch = nonzero_mask15(nb ^ sgbest);
-        // rows beyond the pair's target are padding
-        if (i > TA) ch &= 0xFFFF0000u;
-        if (i > TB) ch &= 0x0000FFFFu;
-        sgbest = bfi(ch, nb, sgbest);
-        sgrow2 = bfi(ch, rep2(i), sgrow2);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint32_t i = i0 + 1 + k;
-        if (i == TA) final2 = (final2 & 0xFFFF0000u) | (Hc[k] & 0x0000FFFFu);
-        if (i == TB) final2 = (final2 & 0x0000FFFFu) | (Hc[k] & 0xFFFF0000u);
-      }
-    }
+  for (uint32_t s = 0; s < nfull; ++s)
+    lane_pk16_strip<MODE, K, K, SH>(a, x, s, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
+  if (rem) {
+    if (rem <= 16)
+      lane_pk16_strip<MODE, 16, K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
+    else if (rem <= 32 || K <= 32)
+      lane_pk16_strip<MODE, (K < 32 ? K : 32), K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
+    else if (rem <= 48 || K <= 48)
+      lane_pk16_strip<MODE, (K < 48 ? K : 48), K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
+    else
+      lane_pk16_strip<MODE, K, K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
   }
 
   // unpack the two pairs' results
@@ -257,20 +305,20 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
     int score;
     uint32_t ei, er;
     if (MODE == SA_LOCAL) {
-      score = (int)(((best >> sh) & 0xFFFFu) >> 6) - (int)bias;
-      ei = (bi2 >> sh) & 0xFFFFu;
-      er = (br2 >> sh) & 0xFFFFu;
+      score = (int)(((st.best >> sh) & 0x7FFFu) >> 6) - (int)bias;
+      ei = (st.bi2 >> sh) & 0xFFFFu;
+      er = (st.br2 >> sh) & 0xFFFFu;
     } else if (MODE == SA_SEMIGLOBAL) {
-      ei = (sgrow2 >> sh) & 0xFFFFu;
+      ei = (st.sgrow2 >> sh) & 0xFFFFu;
       er = Q;
-      score = ei ? (int)((sgbest >> sh) & 0x7FFFu) - (int)bias - gap : border_row0<MODE>((int)Q, gap);
+      score = ei ? (int)((st.sgbest >> sh) & 0x7FFFu) - (int)bias - gap : border_row0<MODE>((int)Q, gap);
     } else {
       ei = T;
       er = Q;
       if (Q == 0 || T == 0)
         score = (T == 0) ? border_row0<MODE>((int)Q, gap) : border_col0<MODE>((int)T, gap);
       else
-        score = (int)((final2 >> sh) & 0x7FFFu) - (int)bias - gap;
+        score = (int)((st.final2 >> sh) & 0x7FFFu) - (int)bias - gap;
     }
     a.score[p] = score;
     a.end_i[pl] = ei;
