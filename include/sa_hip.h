@@ -140,8 +140,11 @@ void sa_free(void* p);
  * sequence s owns triples [d_out_off[s], d_out_off[s+1]) of d_out.  out_capacity is in triples;
  * sa_minimize_out_capacity() gives a sufficient value.  d_status (one int, optional) receives SA_OK,
  * SA_ERR_CAPACITY or SA_ERR_RANGE, written by the device when the work completes.
- * Requires 1 <= k <= 16, 1 <= w <= k + 1 and every length >= k + w - 1 (outside that the reference reads
- * out of bounds; the call is rejected with SA_ERR_ARGUMENT).
+ * Requires 1 <= k <= 16, w >= 1, every length >= k + w - 1 and, for SA_MIN_BINARY, w <= k + 1 (outside that
+ * the reference reads out of bounds; the call is rejected with SA_ERR_ARGUMENT).  SA_MIN_DECIMAL with
+ * k > 10 is rejected with SA_ERR_RANGE (every 11-digit value overflows the reference's stoi unless it
+ * starts with zeros); for k = 10 the range is checked per k-mer on the device (d_status).
+ * d_seq must be 8-byte aligned and readable up to the next multiple of 8 past off[n].
  * ------------------------------------------------------------------------------------------- */
 typedef struct sa_minimize_batch {
   const uint8_t* d_seq;

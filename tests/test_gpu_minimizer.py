@@ -1,0 +1,100 @@
+"""GPU parity tests for batched MinimizeBinary()/Minimize(): the HIP path (through the C-ABI) against
+the golden fixtures produced by the compiled reference and against the CPU restatement.  Bit-exact bar:
+identical (value, position, strand) lists in identical order."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+
+def _tl(arr):
+    return [tuple(int(x) for x in r) for r in arr]
+
+
+def test_reference_unit_test_answers():
+    from sequencealigner_amd.minimize import Minimize, MinimizeBinary
+    # test/testAlignmentMinimizer.cpp:37-57 and :61-82
+    assert MinimizeBinary("TGACGTACATGGACA", 15, 3, 4) == [(2, 10, False), (6, 4, False), (6, 7, True), (11, 1, False)]
+    assert Minimize("TGACGTACATGGACA", 15, 3, 4) == [(2, 10, False), (12, 4, False), (12, 7, True), (23, 1, False)]
+
+
+def test_golden_cases_one_batch_per_kw():
+    from sequencealigner_amd import capi, minimize
+    cases = golden_io.load("minimizer_cases.json")
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["variant"], c["k"], c["w"]), []).append(c)
+    n = 0
+    for (variant, k, w), cs in groups.items():
+        v = capi.SA_MIN_BINARY if variant == "binary" else capi.SA_MIN_DECIMAL
+        throwers = [c for c in cs if c["out"] == "throws"]
+        ok = [c for c in cs if c["out"] != "throws"]
+        if ok:
+            res = minimize.minimize_batch([c["seq"] for c in ok], k, w, v)
+            for c, r in zip(ok, res):
+                assert _tl(r) == [tuple(x) for x in c["out"]], (c["seq"], k, w, variant)
+                n += 1
+        for c in throwers:
+            with pytest.raises(OverflowError):
+                minimize.Minimize(c["seq"], len(c["seq"]), k, w)
+            n += 1
+    assert n == len(cases)
+
+
+def test_golden_long_sequences():
+    from sequencealigner_amd import minimize
+    for c in golden_io.load("minimizer_long.json"):
+        arr = minimize.minimize_binary(golden_io.long_sequence(c["name"]), c["k"], c["w"])
+        assert arr.shape[0] == c["count"], c["name"]
+        assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == c["sha256"], c["name"]
+
+
+def test_random_vs_oracle(oracle):
+    from sequencealigner_amd import minimize
+    rng = random.Random(99)
+    for _ in range(40):
+        k = rng.randint(1, 16)
+        w = rng.randint(1, k + 1)
+        seqs = []
+        for _ in range(rng.randint(1, 60)):
+            L = rng.randint(k + w - 1, k + w - 1 + rng.choice([0, 3, 100, 3000, 7000]))
+            alpha = rng.choice(["ACGT", "ACGT", "acgt", "AC", "A"])
+            if rng.random() < 0.3:
+                unit = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 9)))
+                s = (unit * (L // len(unit) + 1))[:L]
+            else:
+                s = "".join(rng.choice(alpha) for _ in range(L))
+            seqs.append(s)
+        res = minimize.minimize_batch(seqs, k, w)
+        for s, r in zip(seqs, res):
+            assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s))
+
+
+def test_genome_and_reads_shapes_vs_oracle(oracle):
+    from sequencealigner_amd import minimize, synth
+    g = bytes(synth.genome(1_000_000, seed=71)) + b"G" * 40000 + bytes(synth.genome(200_000, seed=72)) \
+        + b"ACT" * 20000 + bytes(synth.genome(100_000, seed=73))
+    got = minimize.minimize_binary(g, 15, 5)
+    want = oracle.minimize_binary_array(g, 15, 5)
+    assert np.array_equal(got, want)
+    reads = synth.reads(300, 10_000, seed=74)
+    res = minimize.minimize_batch(reads, 15, 5)
+    for i in range(0, 300, 17):
+        assert np.array_equal(res[i], oracle.minimize_binary_array(bytes(reads[i]), 15, 5))
+
+
+def test_sortedness_and_uniqueness_property():
+    """Size-independent property on a larger batch: every output list is strictly increasing in
+    (value, position, strand) and every position lies inside its sequence."""
+    from sequencealigner_amd import minimize, synth
+    reads = synth.reads(2000, 10_000, seed=75)
+    res = minimize.minimize_batch(reads, 15, 5)
+    for r in res[::97]:
+        key = (r[:, 0].astype(np.uint64) << np.uint64(33)) | (r[:, 1].astype(np.uint64) << np.uint64(1)) | r[:, 2].astype(np.uint64)
+        assert (np.diff(key.astype(np.int64)) > 0).all()
+        assert r[:, 1].max() <= 10_000 - 15
