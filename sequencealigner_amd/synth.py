@@ -107,5 +107,7 @@ def to_blob(rows):
     lens = np.array([len(r) for r in rows], dtype=np.uint64)
     off = np.zeros(len(rows) + 1, dtype=np.uint64)
     np.cumsum(lens, out=off[1:])
-    blob = np.concatenate([np.asarray(r, dtype=np.uint8) for r in rows]) if len(rows) else np.zeros(0, np.uint8)
+    rows = [np.frombuffer(bytes(r), dtype=np.uint8) if isinstance(r, (bytes, bytearray, str)) else
+            np.asarray(r, dtype=np.uint8) for r in rows]
+    blob = np.concatenate(rows) if len(rows) else np.zeros(0, np.uint8)
     return blob, off
