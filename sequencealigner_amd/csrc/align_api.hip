@@ -2,9 +2,11 @@
 #include "align_common.h"
 #include "align_lane_i32.h"
 #include "align_lane_pk16.h"
+#include "align_wave_i32.h"
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace sa {
@@ -29,7 +31,7 @@ namespace {
 constexpr int kLaneI32K = 32;     // target rows per register strip of the 32-bit lane kernel
 constexpr uint32_t kBlock = 256;  // threads per workgroup of the lane kernels
 
-enum class Family { LaneI32, LanePk16 };
+enum class Family { LaneI32, LanePk16, WaveI32 };
 
 struct Plan {
   Family family;
@@ -89,7 +91,20 @@ Plan make_plan(const sa_align_batch& b) {
   uint32_t bias = 0;
   const int K16 = pk16_strip_rows();
   const bool force_i32 = getenv("SA_FORCE_I32") != nullptr;
-  if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
+  const char* force_family = getenv("SA_FORCE_FAMILY");
+  // Long pairs, or too few pairs to fill the lanes of the inter-pair kernels: one pair per wavefront.
+  const bool want_wave = force_family ? !strcmp(force_family, "wave")
+                                      : (max_q > 2048 || max_t > 2048 || (b.n < 2048 && max_q >= 64));
+  // (SA_FORCE_FAMILY=lane|wave is a test hook that pins the choice.)
+  if (want_wave) {
+    pl.family = Family::WaveI32;
+    pl.name = "wave_i32";
+    pl.K = kWaveCols;
+    pl.nstrips = (max_q + kWaveStrip - 1) / kWaveStrip;
+    pl.pairs_per_unit = 1;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64;
+    pl.brow_unit_stride = round_up((size_t)max_t + 1, 64) + 64;
+  } else if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
     pl.family = Family::LanePk16;
     pl.name = "lane_pk16";
     pl.K = K16;
@@ -199,9 +214,29 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
 }
 
 template <int MODE>
+int launch_wave_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback) {
+  {
+    Timed tm(stream, 1);
+    hipLaunchKernelGGL((fill_wave_i32<MODE>), dim3((a.pairs_in_pass + 3) / 4), dim3(kBlock), 0, stream, a);
+  }
+  SA_HIP_TRY(hipGetLastError());
+  if (need_traceback) {
+    WaveI32Layout lay{a.dirs, a.dirs_unit_stride, a.max_t + 64};
+    {
+      Timed tm(stream, 2);
+      hipLaunchKernelGGL((traceback_kernel<MODE, WaveI32Layout>), dim3((a.pairs_in_pass + 63) / 64),
+                         dim3(64), 0, stream, a, lay);
+    }
+    SA_HIP_TRY(hipGetLastError());
+  }
+  return SA_OK;
+}
+
+template <int MODE>
 int launch_pass(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk, hipStream_t stream,
                 bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
+  if (pl.family == Family::WaveI32) return launch_wave_i32<MODE>(a, stream, need_tb);
   switch (pl.K) {
     case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, stream, need_tb);
     case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, stream, need_tb);

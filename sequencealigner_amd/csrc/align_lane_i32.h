@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void fill_lane_i32(AlignArgs a) {
     int top_prev = (i0 == 0) ? 0 : border_col0<MODE>((int)i0, gap);  // H[i0][0]
     for (uint32_t r = 1; r <= maxQ; ++r) {
       const int qc = r <= Q ? (int)q[r - 1] : 512;
-      const int top = (s == 0) ? border_row0<MODE>((int)r, gap) : brow[(uint64_t)r * 64 + lane];
+      // (read past this CU's L1: the row was read and then overwritten while the previous strip ran)
+      const int top = (s == 0) ? border_row0<MODE>((int)r, gap)
+                               : __hip_atomic_load(&brow[(uint64_t)r * 64 + lane], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
       int diag = top_prev, up = top;
       uint32_t word = 0;
 #pragma unroll

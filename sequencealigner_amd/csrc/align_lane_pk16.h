@@ -158,7 +158,10 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
   for (uint32_t r = 1; r <= maxQ; ++r) {
     const uint32_t qcur = qq;
     if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch the next column's symbols
-    const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap) : brow[(uint64_t)r * 64];
+    // (read past this CU's L1: the row was read and then overwritten while the previous strip ran)
+    const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap)
+                                  : __hip_atomic_load(&brow[(uint64_t)r * 64], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
     uint32_t dsrc = top_prev, up = top;
     const uint32_t best_before = best;
 #pragma unroll

@@ -34,7 +34,24 @@ def _grouped(cases):
     return groups.values()
 
 
-def test_golden_align_cases():
+def _force_family(name):
+    """Pins the kernel family the dispatcher may choose ("lane": the inter-pair lane kernels, packed
+    16-bit where exact, else 32-bit; "wave": one pair per wavefront); None restores automatic choice."""
+    import os
+    if name is None:
+        os.environ.pop("SA_FORCE_FAMILY", None)
+    else:
+        os.environ["SA_FORCE_FAMILY"] = name
+
+
+@pytest.fixture(params=["auto", "lane", "wave"])
+def family(request):
+    _force_family(None if request.param == "auto" else request.param)
+    yield request.param
+    _force_family(None)
+
+
+def test_golden_align_cases(family):
     n = 0
     for g in _grouped(golden_io.load("align_cases.json")):
         _run_group(g)
@@ -42,7 +59,7 @@ def test_golden_align_cases():
     assert n > 500
 
 
-def test_golden_benchmark_shapes():
+def test_golden_benchmark_shapes(family):
     for g in _grouped(golden_io.load("align_shapes.json")):
         _run_group(g)
 
@@ -72,7 +89,7 @@ def _oracle_cases(oracle, pairs, typ, m, x, g):
     return out
 
 
-def test_ragged_random_vs_oracle(oracle):
+def test_ragged_random_vs_oracle(oracle, family):
     rng = random.Random(4242)
     pairs = []
     for _ in range(700):
@@ -97,7 +114,7 @@ def test_ragged_random_vs_oracle(oracle):
     assert n > 10000
 
 
-def test_uniform_shapes_vs_oracle(oracle):
+def test_uniform_shapes_vs_oracle(oracle, family):
     from sequencealigner_amd import synth
     q, t = synth.pairs_short_read_window(300, seed=5)
     pairs = [(bytes(a).decode(), bytes(b).decode()) for a, b in zip(q, t)]
@@ -149,3 +166,22 @@ def test_full_size_properties():
     assert q_used.max() <= 150 and t_used.max() <= 300
     tb = b.target_begins().astype(np.int64)
     assert ((tb + t_used) <= 300).all()
+
+
+def test_long_pairs_vs_oracle(oracle):
+    """Pairs long enough to need several 1024-column strips and the in-memory boundary column."""
+    from sequencealigner_amd import align, synth
+    q, t = synth.pairs_semiglobal_long(6, seed=21, read_len=2500, window_len=2800, lead=120)
+    pairs = [(bytes(a).decode(), bytes(b).decode()) for a, b in zip(q, t)]
+    for typ, (m, x, g) in ((2, (1, -1, -1)), (0, (1, -1, -1)), (1, (2, -3, -2)), (0, (1, -1, 0))):
+        cases = _oracle_cases(oracle, pairs, typ, m, x, g)
+        assert len(cases) == 6
+        b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
+        assert b.kernel_name() == "wave_i32"
+        _run_group(cases)
+    # one pair with unequal lengths, crossing a strip boundary exactly (2048 columns) and not (2049)
+    for ql in (2048, 2049, 1025):
+        qq, tt = synth.pair_global_long(ql, seed=ql)
+        tt = tt[:ql - 37]
+        for typ in (0, 1, 2):
+            _run_group(_oracle_cases(oracle, [(bytes(qq).decode(), bytes(tt).decode())], typ, 1, -1, -1))
