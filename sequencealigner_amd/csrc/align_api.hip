@@ -30,6 +30,7 @@ namespace {
 
 constexpr int kLaneI32K = 32;     // target rows per register strip of the 32-bit lane kernel
 constexpr uint32_t kBlock = 256;  // threads per workgroup of the lane kernels
+constexpr size_t kFixedWorkspace = 1024;  // head of the workspace: AlphabetInfo
 
 enum class Family { LaneI32, LanePk16, WaveI32 };
 
@@ -43,6 +44,8 @@ struct Plan {
   uint64_t dirs_unit_stride;  // dwords per unit
   uint64_t brow_unit_stride;  // ints per unit
   uint64_t qpk_unit_words, tpk_unit_words;
+  bool tables;                // packed kernels: the score-table form may be used (mismatch >= gap, bytes)
+  uint32_t entry_match, entry_mismatch;
   size_t bytes_per_block;     // workspace bytes per workgroup (4 units)
   uint32_t pairs_per_block;
   const char* name;
@@ -80,7 +83,7 @@ int pk16_strip_rows() {
   static int k = [] {
     const char* e = getenv("SA_PK16_K");
     int v = e ? atoi(e) : 48;
-    return (v == 32 || v == 48 || v == 64) ? v : 48;
+    return (v == 48 || v == 64) ? v : 48;
   }();
   return k;
 }
@@ -117,6 +120,11 @@ Plan make_plan(const sa_align_batch& b) {
     pl.brow_unit_stride = (uint64_t)(max_q + 1) * 64;
     pl.qpk_unit_words = (uint64_t)max_q * 64;
     pl.tpk_unit_words = (uint64_t)pl.t_pad * 64;
+    const int sh = (b.type == SA_LOCAL) ? 6 : 0;
+    const long em = ((long)b.match - b.gap) << sh, ex = ((long)b.mismatch - b.gap) << sh;
+    pl.tables = ex >= 0 && em <= 255 && !getenv("SA_NO_TABLES");
+    pl.entry_match = (uint32_t)em;
+    pl.entry_mismatch = (uint32_t)(ex >= 0 ? ex : 0);
   } else {
     pl.family = Family::LaneI32;
     pl.name = "lane_i32";
@@ -186,20 +194,25 @@ int launch_lane_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback)
 
 template <int MODE, int K>
 int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
-                     hipStream_t stream, bool need_traceback) {
+                     const AlphabetInfo* alpha, hipStream_t stream, bool need_traceback) {
   const uint32_t units = (a.pairs_in_pass + 127) / 128;
   {
     Timed tm(stream, 0);
-    hipLaunchKernelGGL(pack_lane_pk16, dim3((a.max_q + 63) / 64, units), dim3(256), 0, stream, a.q,
-                       a.q_off, a.pair_base, a.pairs_in_pass, a.max_q, kQueryPad, qpk);
-    hipLaunchKernelGGL(pack_lane_pk16, dim3((pl.t_pad + 63) / 64, units), dim3(256), 0, stream, a.t,
-                       a.t_off, a.pair_base, a.pairs_in_pass, pl.t_pad, kTargetPad, tpk);
+    PackArgs pk{a.q, a.q_off, a.t, a.t_off, a.pair_base, a.pairs_in_pass, a.max_q, pl.t_pad,
+                (a.max_q + kPackTile - 1) / kPackTile, qpk, tpk, alpha};
+    hipLaunchKernelGGL(pack_lane_pk16, dim3(pk.q_tiles + (pl.t_pad + kPackTile - 1) / kPackTile, units),
+                       dim3(256), 0, stream, pk);
   }
   SA_HIP_TRY(hipGetLastError());
-  Pk16Args x{qpk, tpk, pl.t_pad, pl.bias, units};
+  Pk16Args x{qpk, tpk, pl.t_pad, pl.bias, units, alpha, pl.entry_match, pl.entry_mismatch};
   {
     Timed tm(stream, 1);
-    hipLaunchKernelGGL((fill_lane_pk16<MODE, K>), dim3((units + 3) / 4), dim3(kBlock), 0, stream, a, x);
+    if (alpha)
+      hipLaunchKernelGGL((fill_lane_pk16<MODE, K, true>), dim3((units + 3) / 4), dim3(kBlock), 0, stream,
+                         a, x);
+    else
+      hipLaunchKernelGGL((fill_lane_pk16<MODE, K, false>), dim3((units + 3) / 4), dim3(kBlock), 0,
+                         stream, a, x);
   }
   SA_HIP_TRY(hipGetLastError());
   if (need_traceback) {
@@ -233,14 +246,13 @@ int launch_wave_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback)
 }
 
 template <int MODE>
-int launch_pass(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk, hipStream_t stream,
-                bool need_tb) {
+int launch_pass(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
+                const AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32) return launch_wave_i32<MODE>(a, stream, need_tb);
   switch (pl.K) {
-    case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, stream, need_tb);
-    case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, stream, need_tb);
-    default: return launch_lane_pk16<MODE, 48>(pl, a, qpk, tpk, stream, need_tb);
+    case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb);
+    default: return launch_lane_pk16<MODE, 48>(pl, a, qpk, tpk, alpha, stream, need_tb);
   }
 }
 
@@ -294,8 +306,8 @@ size_t sa_align_workspace_bytes(const sa_align_batch* b, size_t* min_bytes) {
   if (!b) return 0;
   Plan pl = make_plan(*b);
   const size_t blocks = ((size_t)b->n + pl.pairs_per_block - 1) / pl.pairs_per_block;
-  if (min_bytes) *min_bytes = pl.bytes_per_block;
-  return pl.bytes_per_block * (blocks ? blocks : 1);
+  if (min_bytes) *min_bytes = pl.bytes_per_block + kFixedWorkspace;
+  return pl.bytes_per_block * (blocks ? blocks : 1) + kFixedWorkspace;
 }
 
 const char* sa_align_kernel_name(const sa_align_batch* b) {
@@ -320,17 +332,29 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   hipStream_t stream = (hipStream_t)stream_;
 
   const Plan pl = make_plan(*b);
-  if (!d_workspace || workspace_bytes < pl.bytes_per_block)
+  if (!d_workspace || workspace_bytes < pl.bytes_per_block + kFixedWorkspace)
     return fail(SA_ERR_WORKSPACE, "workspace of %zu bytes is below the minimum %zu", workspace_bytes,
-                pl.bytes_per_block);
+                pl.bytes_per_block + kFixedWorkspace);
   const size_t total_blocks = ((size_t)b->n + pl.pairs_per_block - 1) / pl.pairs_per_block;
-  size_t blocks_per_pass = workspace_bytes / pl.bytes_per_block;
+  size_t blocks_per_pass = (workspace_bytes - kFixedWorkspace) / pl.bytes_per_block;
   if (blocks_per_pass > total_blocks) blocks_per_pass = total_blocks;
   const size_t units_per_pass = blocks_per_pass * (kBlock / 64);
   const size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 
   // carve the workspace
-  char* w = (char*)d_workspace;
+  static_assert(sizeof(AlphabetInfo) <= kFixedWorkspace, "fixed workspace too small");
+  AlphabetInfo* alpha = nullptr;
+  if (pl.family == Family::LanePk16 && pl.tables) {
+    // device-side decision, uniform for the call: at most four distinct symbols -> score tables
+    alpha = (AlphabetInfo*)d_workspace;
+    SA_HIP_TRY(hipMemsetAsync(alpha, 0, sizeof(AlphabetInfo), stream));
+    Timed tm(stream, 0);
+    hipLaunchKernelGGL(alphabet_scan, dim3(2048), dim3(256), 0, stream, b->d_q, b->d_q_off, b->d_t,
+                       b->d_t_off, b->n, alpha);
+    hipLaunchKernelGGL(alphabet_table, dim3(1), dim3(256), 0, stream, alpha);
+    SA_HIP_TRY(hipGetLastError());
+  }
+  char* w = (char*)d_workspace + kFixedWorkspace;
   AlignArgs a{};
   a.q = b->d_q;
   a.q_off = b->d_q_off;
@@ -369,11 +393,11 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
     a.pairs_in_pass = (uint32_t)((b->n - base) < pairs_per_pass ? (b->n - base) : pairs_per_pass);
     int rc;
     if (b->type == SA_GLOBAL)
-      rc = launch_pass<SA_GLOBAL>(pl, a, qpk, tpk, stream, need_tb);
+      rc = launch_pass<SA_GLOBAL>(pl, a, qpk, tpk, alpha, stream, need_tb);
     else if (b->type == SA_LOCAL)
-      rc = launch_pass<SA_LOCAL>(pl, a, qpk, tpk, stream, need_tb);
+      rc = launch_pass<SA_LOCAL>(pl, a, qpk, tpk, alpha, stream, need_tb);
     else
-      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, qpk, tpk, stream, need_tb);
+      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, qpk, tpk, alpha, stream, need_tb);
     if (rc) return rc;
   }
   return SA_OK;

@@ -61,11 +61,29 @@ __device__ __forceinline__ uint32_t nonzero_mask15(uint32_t v) {
 }
 
 struct Pk16Args {
-  const uint32_t* qpk;  // [unit][max_q][64]  query symbols, pair A in the low half, pair B in the high
-  const uint32_t* tpk;  // [unit][t_pad][64]  target symbols
+  // Packed sequences, written by pack_lane_pk16 in one of two forms (see AlphabetInfo::small):
+  //  symbols: qpk[unit][max_q][64] dwords, tpk[unit][t_pad][64] dwords - the byte of pair A in the low
+  //           half, of pair B in the high half (pads: kQueryPad / kTargetPad);
+  //  tables:  qpk[unit][max_q][64] dwords - the symbol CODES (0..3) of the two pairs in the halves, 0xFFFF
+  //           beyond the query; per column the fill expands each code into a 4-byte table whose byte L is
+  //           (sub(L, q) - gap) << SH (all 0 beyond the query);
+  //           tpk[unit][t_pad][64] dwords - v_perm selectors {code A, 0x0C, 4 + code B, 0x0C} that pick
+  //           the pair's entry out of {table B, table A} (0x0C = constant 0, also used beyond the target).
+  const uint32_t* qpk;
+  const uint32_t* tpk;
   uint32_t t_pad;       // nstrips * K
   uint32_t bias;        // BIAS
   uint32_t units;       // waves of 128 pairs in this pass
+  const struct AlphabetInfo* alpha;  // NULL: symbols form only
+  uint32_t entry_match, entry_mismatch;  // tables form: (match - gap) << SH, (mismatch - gap) << SH
+};
+
+// Result of scanning a batch's bytes: with at most four distinct symbols the substitution score of a
+// cell is a table lookup (one v_perm_b32) instead of compare + select arithmetic.
+struct AlphabetInfo {
+  uint32_t present[8];  // bit b set: byte value b occurs in the batch
+  uint32_t small;       // 1: at most 4 distinct bytes, code[] maps them to 0..3
+  uint8_t code[256];
 };
 
 // Number of direction dwords a lane writes per query column and strip: 2 planes per group of 16 rows.
@@ -104,7 +122,7 @@ struct LanePk16State {
 // One strip of KS target rows (rows i0+1 .. i0+KS) over all query columns.  KMAX (>= KS) is the
 // strip height the direction tiles and the LDS staging area are laid out for.  SH is the left shift
 // applied to every score (6 for Local, where the low 6 bits of the best-cell key hold the row).
-template <int MODE, int KS, int KMAX, int SH>
+template <int MODE, int KS, int KMAX, int SH, bool PERM>
 __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Args& x, uint32_t s,
                                                 uint32_t nstrips, uint32_t maxQ, uint32_t lane,
                                                 const uint32_t* qpk, const uint32_t* tpk, uint32_t* brow,
@@ -154,10 +172,18 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
   uint32_t top_prev = SG(((i0 == 0) ? 0 : border_col0<MODE>((int)i0, gap)) + gap);
   const uint32_t best_strip0 = st.best;
   uint32_t best = st.best;
+  const uint32_t tab_base = x.entry_mismatch * 0x01010101u;
+  const uint32_t tab_delta = x.entry_match - x.entry_mismatch;
   uint32_t qq = qpk[0];
   for (uint32_t r = 1; r <= maxQ; ++r) {
-    const uint32_t qcur = qq;
-    if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch the next column's symbols
+    // symbols form: x = the two pairs' query symbols; tables form: (x, y) = the two pairs' score tables
+    uint2 qcur = make_uint2(qq, 0);
+    if (PERM) {
+      const uint32_t ca = qq & 0xFFFFu, cb = qq >> 16;
+      qcur.x = ca > 3 ? 0u : tab_base + (tab_delta << (8 * ca));
+      qcur.y = cb > 3 ? 0u : tab_base + (tab_delta << (8 * cb));
+    }
+    if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch the next column
     // (read past this CU's L1: the row was read and then overwritten while the previous strip ran)
     const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap)
                                   : __hip_atomic_load(&brow[(uint64_t)r * 64], __ATOMIC_RELAXED,
@@ -175,8 +201,13 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
         const int k = c0 + j;
         if (k >= KS) break;
         const uint32_t base = (j == 0) ? dsrc : Hc[k - 1];
-        const uint32_t ne = pk_min_u16(Tk[k] ^ qcur, one2);  // 1 where the symbols differ
-        dG[j] = pk_mad_u16(ne, negdelta2, base + mg2);
+        if (PERM) {
+          // base = S(H[i-1][r-1] + gap); the table entry is (sub - gap) << SH >= 0
+          dG[j] = base + __builtin_amdgcn_perm(qcur.y, qcur.x, Tk[k]);
+        } else {
+          const uint32_t ne = pk_min_u16(Tk[k] ^ qcur.x, one2);  // 1 where the symbols differ
+          dG[j] = pk_mad_u16(ne, negdelta2, base + mg2);
+        }
       }
       // previous column's value of the chunk's last row, for the next chunk
       dsrc = Hc[(c0 + CHMAX < KS ? c0 + CHMAX : KS) - 1];
@@ -238,7 +269,35 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
   }
 }
 
-template <int MODE, int K>
+// All strips of one unit: full strips of K rows, then one strip of 16/32/48 rows for the remainder.
+template <int MODE, int K, int SH, bool PERM>
+__device__ __forceinline__ void lane_pk16_strips(const AlignArgs& a, const Pk16Args& x, uint32_t nfull,
+                                                 uint32_t rem, uint32_t nstrips, uint32_t maxQ,
+                                                 uint32_t lane, const uint32_t* qpk, const uint32_t* tpk,
+                                                 uint32_t* brow, uint32_t* dirs, uint2* stage,
+                                                 uint32_t TA, uint32_t TB, LanePk16State& st) {
+  for (uint32_t s = 0; s < nfull; ++s)
+    lane_pk16_strip<MODE, K, K, SH, PERM>(a, x, s, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA,
+                                          TB, st);
+  if (rem) {
+    if (rem <= 16)
+      lane_pk16_strip<MODE, 16, K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
+                                             stage, TA, TB, st);
+    else if (rem <= 32 || K <= 32)
+      lane_pk16_strip<MODE, (K < 32 ? K : 32), K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk,
+                                                            brow, dirs, stage, TA, TB, st);
+    else if (rem <= 48 || K <= 48)
+      lane_pk16_strip<MODE, (K < 48 ? K : 48), K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk,
+                                                            brow, dirs, stage, TA, TB, st);
+    else
+      lane_pk16_strip<MODE, K, K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
+                                            stage, TA, TB, st);
+  }
+}
+
+// TABLES: the launch may use the score-table form of the packed sequences (decided by the device-side
+// alphabet scan); without it only the symbols form is compiled in.
+template <int MODE, int K, bool TABLES>
 __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   constexpr int NG = LanePk16Geom<K>::NG;
   constexpr int SH = (MODE == SA_LOCAL) ? 6 : 0;
@@ -269,10 +328,9 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   const uint32_t nfull = maxT / K, rem = maxT - nfull * K;
   const uint32_t nstrips = nfull + (rem ? 1 : 0);
 
-  const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
-  const uint32_t* tpk = x.tpk + (uint64_t)unit * x.t_pad * 64 + lane;
   uint32_t* brow = reinterpret_cast<uint32_t*>(a.brow) + (uint64_t)unit * a.brow_unit_stride + lane;
   uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride;
+  const uint32_t* tpk = x.tpk + (uint64_t)unit * x.t_pad * 64 + lane;
 
   const int gap = a.gap;
   const uint32_t bias = x.bias;
@@ -283,17 +341,16 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   st.sgrow2 = 0;
   st.final2 = 0;
 
-  for (uint32_t s = 0; s < nfull; ++s)
-    lane_pk16_strip<MODE, K, K, SH>(a, x, s, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
-  if (rem) {
-    if (rem <= 16)
-      lane_pk16_strip<MODE, 16, K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
-    else if (rem <= 32 || K <= 32)
-      lane_pk16_strip<MODE, (K < 32 ? K : 32), K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
-    else if (rem <= 48 || K <= 48)
-      lane_pk16_strip<MODE, (K < 48 ? K : 48), K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
-    else
-      lane_pk16_strip<MODE, K, K, SH>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA, TB, st);
+  // The batch scan decides (on the device, uniformly for the launch) which packed form was written.
+  const bool tables = TABLES && x.alpha->small;
+  if (tables) {
+    const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
+    lane_pk16_strips<MODE, K, SH, true>(a, x, nfull, rem, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
+                                        stage, TA, TB, st);
+  } else {
+    const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
+    lane_pk16_strips<MODE, K, SH, false>(a, x, nfull, rem, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
+                                         stage, TA, TB, st);
   }
 
   // unpack the two pairs' results
@@ -434,31 +491,132 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   }
 }
 
-// Transposes the byte sequences of a pass into the lane-interleaved layout the fill kernel reads:
-// out[unit][pos][lane] = symbol of pair (unit*128 + lane) | symbol of pair (unit*128 + 64 + lane) << 16,
-// with `pad` beyond the end of a sequence.  One workgroup per (unit, tile of 64 positions).
-__global__ __launch_bounds__(256) void pack_lane_pk16(const uint8_t* seq, const uint64_t* off,
-                                                      uint32_t pair_base, uint32_t pairs_in_pass,
-                                                      uint32_t len_cap, uint32_t pad, uint32_t* out) {
-  __shared__ uint16_t tile[128][66];
-  const uint32_t unit = blockIdx.y, t0 = blockIdx.x * 64;
+// Marks which byte values occur in the query and target blobs of a batch (grid-stride over bytes).
+__global__ __launch_bounds__(256) void alphabet_scan(const uint8_t* q, const uint64_t* q_off,
+                                                     const uint8_t* t, const uint64_t* t_off, uint32_t n,
+                                                     AlphabetInfo* info) {
+  uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const uint8_t* base = which ? t : q;
+    const uint64_t b0 = which ? t_off[0] : q_off[0], b1 = which ? t_off[n] : q_off[n];
+    // 8 bytes per thread and iteration through aligned loads (the blob is 8-byte aligned and readable
+    // up to the next multiple of 8 past its end)
+    const uint64_t w0 = b0 & ~7ull, w1 = (b1 + 7) & ~7ull;
+    for (uint64_t w = w0 + 8 * tid; w < w1; w += 8 * nthreads) {
+      const uint64_t word = *reinterpret_cast<const uint64_t*>(base + w);
+      const bool inner = w >= b0 && w + 8 <= b1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (!inner && (w + j < b0 || w + j >= b1)) continue;
+        const uint32_t c = (uint32_t)(word >> (8 * j)) & 0xFFu;
+        const uint64_t bit = 1ull << (c & 63);
+        const uint32_t hi = c >> 6;
+        m0 |= hi == 0 ? bit : 0;
+        m1 |= hi == 1 ? bit : 0;
+        m2 |= hi == 2 ? bit : 0;
+        m3 |= hi == 3 ? bit : 0;
+      }
+    }
+  }
+  uint32_t words[8] = {(uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32),
+                       (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)m3, (uint32_t)(m3 >> 32)};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t v = words[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(&info->present[i], v);
+  }
+}
+
+// Numbers the symbols that occur (in increasing byte order) when there are at most four of them.
+__global__ void alphabet_table(AlphabetInfo* info) {  // one workgroup of 256 threads
+  const uint32_t b = threadIdx.x;
+  uint32_t below = 0, total = 0;
+#pragma unroll
+  for (uint32_t wd = 0; wd < 8; ++wd) {
+    const uint32_t m = info->present[wd];
+    total += __builtin_popcount(m);
+    if (wd < (b >> 5))
+      below += __builtin_popcount(m);
+    else if (wd == (b >> 5))
+      below += __builtin_popcount(m & ((1u << (b & 31)) - 1u));
+  }
+  const bool on = (info->present[b >> 5] >> (b & 31)) & 1u;
+  info->code[b] = (uint8_t)(on && below < 4 ? below : 0);
+  if (b == 0) info->small = total <= 4 ? 1u : 0u;
+}
+
+// Transposes the byte sequences of a pass into the lane-interleaved layout the fill kernel reads (the
+// two forms are described at Pk16Args).  One workgroup per (unit, tile of 256 positions); blockIdx.x
+// first walks the query tiles, then the target tiles.  Sequence bytes are fetched four at a time
+// (unaligned dword loads; the blobs are readable up to the next multiple of 8 past their end).
+constexpr uint32_t kPackTile = 256;
+
+struct PackArgs {
+  const uint8_t* q;
+  const uint64_t* q_off;
+  const uint8_t* t;
+  const uint64_t* t_off;
+  uint32_t pair_base, pairs_in_pass;
+  uint32_t q_cap, t_cap;     // positions per unit in qpk / tpk
+  uint32_t q_tiles;          // tiles of the query side (the rest of gridDim.x is the target side)
+  uint32_t* qpk;
+  uint32_t* tpk;
+  const AlphabetInfo* alpha;
+};
+
+__global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
+  __shared__ uint8_t tile[128][kPackTile + 4];
+  __shared__ uint8_t code[256];
+  const bool tables = a.alpha && a.alpha->small;
+  const bool is_query = blockIdx.x < a.q_tiles;
+  const uint32_t unit = blockIdx.y;
+  const uint32_t t0 = (is_query ? blockIdx.x : blockIdx.x - a.q_tiles) * kPackTile;
+  const uint8_t* seq = is_query ? a.q : a.t;
+  const uint64_t* off = is_query ? a.q_off : a.t_off;
+  const uint32_t len_cap = is_query ? a.q_cap : a.t_cap;
+  uint32_t* out = is_query ? a.qpk : a.tpk;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (tables) code[threadIdx.x] = a.alpha->code[threadIdx.x];
+  // 0xFF marks "past the end" in the tile (in the tables form real entries are codes 0..3; in the
+  // symbols form the length test below is repeated when writing)
   for (uint32_t pp = wv; pp < 128; pp += 4) {
     const uint32_t pl = unit * 128 + pp;
-    uint16_t v = (uint16_t)pad;
-    if (pl < pairs_in_pass) {
-      const uint64_t b = off[pair_base + pl], e = off[pair_base + pl + 1];
-      const uint64_t pos = b + t0 + lane;
-      if (pos < e) v = seq[pos];
+    uint32_t word = 0;
+    if (pl < a.pairs_in_pass) {
+      const uint64_t b = off[a.pair_base + pl], e = off[a.pair_base + pl + 1];
+      const uint64_t pos = b + t0 + 4 * lane;
+      if (pos < e) word = *reinterpret_cast<const uint32_t*>(seq + pos);
     }
-    tile[pp][lane] = v;
+    *reinterpret_cast<uint32_t*>(&tile[pp][4 * lane]) = word;
   }
   __syncthreads();
-  for (uint32_t c = wv; c < 64; c += 4) {
+  // lengths of this lane's two pairs, to tell real symbols from the bytes behind a sequence
+  uint32_t lenA = 0, lenB = 0;
+  {
+    const uint32_t plA = unit * 128 + lane, plB = plA + 64;
+    if (plA < a.pairs_in_pass) lenA = (uint32_t)(off[a.pair_base + plA + 1] - off[a.pair_base + plA]);
+    if (plB < a.pairs_in_pass) lenB = (uint32_t)(off[a.pair_base + plB + 1] - off[a.pair_base + plB]);
+  }
+  const uint32_t pad = is_query ? kQueryPad : kTargetPad;
+  for (uint32_t c = wv; c < kPackTile; c += 4) {
     const uint32_t pos = t0 + c;
-    if (pos < len_cap)
-      out[((uint64_t)unit * len_cap + pos) * 64 + lane] =
-          (uint32_t)tile[lane][c] | ((uint32_t)tile[lane + 64][c] << 16);
+    if (pos >= len_cap) break;
+    const bool inA = pos < lenA, inB = pos < lenB;
+    const uint32_t ba = tile[lane][c], bb = tile[lane + 64][c];
+    const uint64_t at = ((uint64_t)unit * len_cap + pos) * 64 + lane;
+    if (!tables) {
+      out[at] = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
+    } else if (is_query) {
+      out[at] = (inA ? (uint32_t)code[ba] : 0xFFFFu) | ((inB ? (uint32_t)code[bb] : 0xFFFFu) << 16);
+    } else {
+      const uint32_t sa = inA ? (uint32_t)code[ba] : 0x0Cu, sb = inB ? 4u + code[bb] : 0x0Cu;
+      out[at] = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
+    }
   }
 }
 
