@@ -83,7 +83,7 @@ int pk16_strip_rows() {
   static int k = [] {
     const char* e = getenv("SA_PK16_K");
     int v = e ? atoi(e) : 48;
-    return (v == 48 || v == 64) ? v : 48;
+    return (v == 32 || v == 48 || v == 64) ? v : 48;
   }();
   return k;
 }
@@ -251,6 +251,7 @@ int launch_pass(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32) return launch_wave_i32<MODE>(a, stream, need_tb);
   switch (pl.K) {
+    case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, alpha, stream, need_tb);
     case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb);
     default: return launch_lane_pk16<MODE, 48>(pl, a, qpk, tpk, alpha, stream, need_tb);
   }

@@ -8,10 +8,10 @@
 //   * the register strip runs along the TARGET (K rows), the lane's loop along the QUERY;
 //     Hc[k] holds S(H[i][r-1] + gap) of its row, which serves both as the "left" candidate of the next
 //     column and, shifted by (match - gap), as the "diagonal" base of the row below;
-//   * per cell two flags are kept, A = (max == diag candidate) and B = (max == left candidate); they are
-//     bit 15 of (candidate - max) thanks to the guard bit.  Diag > Left > Up follows from reading A
-//     first, then B.  Local's None state is not stored: a cell is None exactly when its score is 0, which
-//     the traceback knows from the running score.
+//   * per cell two flags are kept, "diag candidate != max" and "left candidate != max": the sign of the
+//     packed difference candidate - max (candidates never exceed the max).  Diag > Left > Up follows
+//     from reading the diag flag first, then the left flag.  Local's None state is not stored: a cell is
+//     None exactly when its score is 0, which the traceback knows from the running score.
 //   * Local's best cell (first strict maximum in row-major order, src/alignment.cpp:203-207) is tracked
 //     with one packed max per cell on the key (S(H) << 6) | (63 - k): larger score first, then smaller
 //     row inside the strip; strips are visited in increasing row order and columns in increasing order.
@@ -50,6 +50,12 @@ __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t 
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
   uint32_t r;
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+// per half: a - b (mod 2^16)
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 __device__ __forceinline__ uint32_t rep2(uint32_t v16) { return (v16 & 0xFFFFu) * 0x00010001u; }
@@ -175,6 +181,9 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
   const uint32_t tab_base = x.entry_mismatch * 0x01010101u;
   const uint32_t tab_delta = x.entry_match - x.entry_mismatch;
   uint32_t qq = qpk[0];
+  uint32_t top_next = 0;
+  if (s != 0)
+    top_next = __hip_atomic_load(&brow[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t r = 1; r <= maxQ; ++r) {
     // symbols form: x = the two pairs' query symbols; tables form: (x, y) = the two pairs' score tables
     uint2 qcur = make_uint2(qq, 0);
@@ -184,10 +193,12 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
       qcur.y = cb > 3 ? 0u : tab_base + (tab_delta << (8 * cb));
     }
     if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch the next column
-    // (read past this CU's L1: the row was read and then overwritten while the previous strip ran)
-    const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap)
-                                  : __hip_atomic_load(&brow[(uint64_t)r * 64], __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
+    // The boundary row of the strip above is fetched one column ahead as well.  (Read past this CU's
+    // L1: the same addresses were read and then overwritten while the previous strip ran.)
+    const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap) : top_next;
+    if (s != 0 && r < maxQ)
+      top_next = __hip_atomic_load(&brow[(uint64_t)(r + 1) * 64], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
     uint32_t dsrc = top_prev, up = top;
     const uint32_t best_before = best;
 #pragma unroll
@@ -211,8 +222,10 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
       }
       // previous column's value of the chunk's last row, for the next chunk
       dsrc = Hc[(c0 + CHMAX < KS ? c0 + CHMAX : KS) - 1];
-      // pass 2: the dependent chain down the column
-      uint32_t accA = 0, accB = 0;
+      // pass 2: the dependent chain down the column.  Flags: candidate - max is negative (bit 15 of the
+      // half set) exactly when the candidate is NOT the maximum; one v_perm turns the four sign bits
+      // (left/diag x pair A/B) into four 0x00/0xFF bytes, of which bit (k % 8) is kept per cell.
+      uint32_t acc0 = 0, acc1 = 0;
 #pragma unroll
       for (int j = 0; j < CHMAX; ++j) {
         const int k = c0 + j;
@@ -223,15 +236,18 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
           mG = pk_max_u16(mG, pk_max_u16(left, floorG));
         else
           mG = pk_max_u16(mG, left);
-        const uint32_t m = mG ^ G;
-        accA = bfi(G, dG[j] - m, accA >> 1);  // bit 15 of (candidate - max) == (candidate == max)
-        accB = bfi(G, left - m, accB >> 1);
+        const uint32_t signs =
+            __builtin_amdgcn_perm(pk_sub_u16(dG[j], mG), pk_sub_u16(left, mG), 0x0B0A0908u);
+        if (j < 8)
+          acc0 |= signs & (0x01010101u << (j & 7));
+        else
+          acc1 |= signs & (0x01010101u << (j & 7));
         if (MODE == SA_LOCAL) best = pk_max_u16(best, mG | rep2(63 - k));
         const uint32_t hg = mG - gsub2;  // S(H[i][r] + gap)
         Hc[k] = hg;
         up = hg;
       }
-      stage[((c0 >> 4) * kColBlock + ((r - 1) & (kColBlock - 1))) * 64 + lane] = make_uint2(accA, accB);
+      stage[((c0 >> 4) * kColBlock + ((r - 1) & (kColBlock - 1))) * 64 + lane] = make_uint2(acc0, acc1);
     }
     if (((r - 1) & (kColBlock - 1)) == kColBlock - 1 || r == maxQ) flush_tiles((r - 1) / kColBlock);
     if (s + 1 < nstrips) brow[(uint64_t)r * 64] = up;
@@ -425,8 +441,6 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
     } else {
       const uint32_t s = (i - 1) / K, k = (i - 1) % K;
       const uint32_t g = k >> 4, j = k & 15;
-      const uint32_t gs = (g == NG - 1) ? (K - 16 * (NG - 1)) : 16;
-      const uint32_t bit = 16 * half + 15 - (gs - 1 - j);
       const uint32_t tile = (s * nrb + (r - 1) / kColBlock) * NG + g;
       if (tile != cached_tile) {
         const uint4* src = reinterpret_cast<const uint4*>(dirs + (uint64_t)tile * 1024);
@@ -438,8 +452,13 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
       }
       const uint32_t c = (r - 1) & (kColBlock - 1);
       const uint4 sel = (c < 4) ? ((c < 2) ? seg0 : seg1) : ((c < 6) ? seg2 : seg3);
-      const uint32_t wa = (c & 1) ? sel.z : sel.x, wb = (c & 1) ? sel.w : sel.y;
-      d = ((wa >> bit) & 1u) ? DIR_DIAG : (((wb >> bit) & 1u) ? DIR_LEFT : DIR_UP);
+      // per column a lane stores two dwords: rows 0-7 and rows 8-15 of the group; byte 2+half holds the
+      // "diagonal candidate is not the maximum" bits, byte half the "left candidate is not" bits
+      const uint32_t w0 = (c & 1) ? sel.z : sel.x, w1 = (c & 1) ? sel.w : sel.y;
+      const uint32_t word = (j < 8) ? w0 : w1;
+      const uint32_t not_diag = (word >> (16 + 8 * half + (j & 7))) & 1u;
+      const uint32_t not_left = (word >> (8 * half + (j & 7))) & 1u;
+      d = !not_diag ? DIR_DIAG : (!not_left ? DIR_LEFT : DIR_UP);
     }
     if (d == DIR_NONE) break;
     uint32_t op;
