@@ -58,6 +58,12 @@ __device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
   asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// (a & mask) | c, with the mask in a scalar register
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(c));
+  return r;
+}
 __device__ __forceinline__ uint32_t rep2(uint32_t v16) { return (v16 & 0xFFFFu) * 0x00010001u; }
 
 // 0x7FFF in every half whose value is non-zero (value < 0x8000), else 0.
@@ -239,9 +245,9 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
         const uint32_t signs =
             __builtin_amdgcn_perm(pk_sub_u16(dG[j], mG), pk_sub_u16(left, mG), 0x0B0A0908u);
         if (j < 8)
-          acc0 |= signs & (0x01010101u << (j & 7));
+          acc0 = and_or(signs, 0x01010101u << (j & 7), acc0);
         else
-          acc1 |= signs & (0x01010101u << (j & 7));
+          acc1 = and_or(signs, 0x01010101u << (j & 7), acc1);
         if (MODE == SA_LOCAL) best = pk_max_u16(best, mG | rep2(63 - k));
         const uint32_t hg = mG - gsub2;  // S(H[i][r] + gap)
         Hc[k] = hg;
