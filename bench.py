@@ -67,6 +67,51 @@ def cpu_baseline(q, t, typ, sample, threads):
             "sample": f"{sample} pairs of the same workload, CIGAR on, {dt:.1f} s"}, scores
 
 
+def minimizer_leg(dev, steps, cpu_threads, with_cpu):
+    """Secondary metric of the same hot path: MinimizeBinary k=15 w=5 on a 4.6 Mbp genome (one sequence)
+    and on 1 Gbp of 10 kbp reads (100 000 sequences), inputs resident in HBM.  Returns a dict."""
+    import torch
+    from sequencealigner_amd import minimize, synth
+    out = {"k": 15, "w": 5}
+    for name, seqs in (("genome_4.6Mbp", [synth.genome(4_600_000, seed=4)]),
+                       ("reads_100k_x_10kbp", synth.reads(100_000, 10_000, seed=6))):
+        b = minimize.DeviceMinimizeBatch(seqs, 15, 5, device=dev)
+        b.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        n_out = int(b.d_out_off[-1].item())
+        bytes_alg = b.total_len + 12 * n_out     # 1 B/base read + 12 B per unique minimizer written
+        out[name] = {"ms": dt * 1e3, "windows_per_s": b.windows / dt, "minimizers_per_s": n_out / dt,
+                     "unique_minimizers": n_out,
+                     "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": bytes_alg / dt / 1e9 / HBM_PEAK_GBS}}
+        if with_cpu and name.startswith("reads"):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import cpu_checker
+            chk = cpu_checker.reference() or cpu_checker.restatement()
+            sample = 2000
+            blob = np.concatenate([np.ascontiguousarray(seqs[:sample]).reshape(sample, -1),
+                                   np.zeros((sample, 1), np.uint8)], axis=1)   # NUL-terminated
+            off = np.arange(sample, dtype=np.uint64) * np.uint64(blob.shape[1])
+            lens = np.full(sample, seqs.shape[1], dtype=np.uint32)
+            t0 = time.perf_counter()
+            counts = chk.minimize_batch(blob.reshape(-1), off, lens, 15, 5, cpu_threads)
+            cdt = time.perf_counter() - t0
+            win = sample * (seqs.shape[1] - 18)
+            out[name]["cpu_baseline"] = {
+                "value": win / cdt, "unit": "windows/s", "cores": cpu_threads,
+                "kind": "reference" if chk.kind == "reference" else "port",
+                "sample": f"{sample} reads of the same workload, {cdt:.1f} s",
+                "counts_equal_gpu": bool(np.array_equal(counts.astype(np.int64), b.counts()[:sample]))}
+        del b
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +122,7 @@ def main():
     ap.add_argument("--no-cigar", action="store_true", help="score only (not the headline number)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-minimizers", action="store_true", help="skip the secondary minimizer metric")
     args = ap.parse_args()
 
     import torch
@@ -161,6 +207,12 @@ def main():
                        "pairs_per_gpu": n, "cells_per_step_per_gpu": cells_rank},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out["dtype"] = "u16x2" if batch.kernel_name() == "lane_pk16" else "int32"
+        if not args.no_minimizers and not world.is_dist:
+            del batch
+            torch.cuda.empty_cache()
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            out["minimizers"] = minimizer_leg(dev, 3, threads, sample != 0)
         print(json.dumps(out), flush=True)
     sdist.finalize(world)
     return out

@@ -144,7 +144,7 @@ void sa_free(void* p);
  * the reference reads out of bounds; the call is rejected with SA_ERR_ARGUMENT).  SA_MIN_DECIMAL with
  * k > 10 is rejected with SA_ERR_RANGE (every 11-digit value overflows the reference's stoi unless it
  * starts with zeros); for k = 10 the range is checked per k-mer on the device (d_status).
- * d_seq must be 8-byte aligned and readable up to the next multiple of 8 past off[n].
+ * d_seq must be readable up to 8 bytes past off[n] (bases are fetched eight at a time).
  * ------------------------------------------------------------------------------------------- */
 typedef struct sa_minimize_batch {
   const uint8_t* d_seq;

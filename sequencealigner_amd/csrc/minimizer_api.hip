@@ -15,90 +15,200 @@ namespace {
 constexpr uint32_t kThreads = 256;
 
 // ---- chunk bookkeeping ---------------------------------------------------------------------------
-__global__ void min_seq_chunks(const uint64_t* off, uint32_t n, uint32_t k, uint32_t w, int variant,
-                               uint32_t* nchunks) {
+__global__ void min_seq_plan(const uint64_t* off, uint32_t n, uint32_t k, uint32_t w, uint32_t chunk,
+                             uint32_t* nchunks, uint32_t* windows) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > n) return;
   if (s == n) {
     nchunks[s] = 0;
+    windows[s] = 0;
     return;
   }
   const uint32_t len = (uint32_t)(off[s + 1] - off[s]);
-  const uint32_t windows = len - w - k + 2;
-  nchunks[s] = (variant == SA_MIN_BINARY) ? (windows + kChunk - 1) / kChunk : 1;
+  const uint32_t win = len - w - k + 2;
+  windows[s] = win;
+  nchunks[s] = (win + chunk - 1) / chunk;
 }
 
-// First pass: proves each chunk's entry state (exactly from the sequence start, or by collapsing the
-// candidate set during the warm-up) and counts the chunk's candidates.
-__global__ __launch_bounds__(kThreads) void min_count(MinArgs a) {
-  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
-  ChunkRef c;
-  if (chunk >= a.max_chunks) return;
-  a.counts[chunk] = 0;
-  a.resolved[chunk] = 1;
-  if (!locate_chunk(a, chunk, &c)) return;
-  const uint32_t k = a.k, w = a.w;
-  uint32_t pf = 0, pc = 0;
-  if (c.first_window > kWarm) {
-    const uint32_t i_s = c.first_window - kWarm;
-    uint32_t j = i_s + w - 1;
-    BaseStream bs;
-    bs.init(a.seq + c.base, (j >= k + 1) ? j - k - 1 : 0, k);
-    uint32_t Mf = (k + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (k + 1)) - 1u);
-    if (j < k + 1) Mf = (1u << j) - 1u;  // only positions >= 0 exist
-    uint32_t Mc = Mf;
-    for (uint32_t i = i_s; i < c.first_window; ++i, ++j) {
-      bs.advance_to((uint64_t)j + k - 1);
-      const uint32_t vj = bs.kmer(j);
-      Mf = step_set<true>(bs, j, k, w, vj, Mf);
-      Mc = step_set<false>(bs, j, k, w, vj, Mc);
-    }
-    if (__builtin_popcount(Mf) != 1 || __builtin_popcount(Mc) != 1) {
-      a.resolved[chunk] = 0;  // left to min_fix
-      return;
-    }
-    pf = j - 1 - __builtin_ctz(Mf);
-    pc = j - 1 - __builtin_ctz(Mc);
-  } else if (c.first_window > 0) {
-    // close to the start of the sequence: run the few windows before the chunk exactly
-    ChunkRef head = c;
-    head.first_window = 0;
-    head.end_window = c.first_window;
-    run_chunk<false>(a, head, pf, pc, nullptr);
+__device__ __forceinline__ uint64_t load8(const uint8_t* p) {  // any alignment
+  return *reinterpret_cast<const uint64_t*>(p);
+}
+
+// Writes the keys the lanes of a wave hold in LDS to their sequences' key ranges.  Lanes are ordered by
+// chunk, so lanes of one sequence are neighbours: the first lane of each run reserves the run's total
+// with one atomic on the sequence's counter.  Must be called by all lanes of the wave.
+__device__ __forceinline__ void flush_keys(const MinArgs& a, uint64_t (*buf)[kThreads], uint32_t tid,
+                                           uint32_t seq, uint32_t slot, uint32_t& cnt) {
+  const uint32_t lane = tid & 63;
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(inc, d);
+    if ((int)lane >= d) inc += v;
   }
-  a.counts[chunk] = run_chunk<false>(a, c, pf, pc, nullptr);
-  a.exit_f[chunk] = pf;
-  a.exit_c[chunk] = pc;
+  const uint32_t excl = inc - cnt;
+  const uint32_t total = __shfl(inc, 63);
+  const uint32_t prev = __shfl_up(seq, 1);
+  const bool head = lane == 0 || prev != seq;
+  const uint64_t heads = __ballot(head);
+  const uint32_t leader = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
+  const uint64_t above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+  const uint32_t next = above ? (uint32_t)__builtin_ctzll(above) : 64u;
+  const uint32_t run_begin = __shfl(excl, leader);
+  uint32_t run_end = __shfl(excl, next & 63);
+  if (next == 64) run_end = total;
+  uint32_t base = 0;
+  if (head && run_end > run_begin) base = atomicAdd(&a.counter[seq], run_end - run_begin);
+  base = __shfl(base, leader);
+  uint64_t* dst = a.keys + slot + base + (excl - run_begin);
+  for (int i = 0; i < kBuf; ++i) {
+    if (!__any((uint32_t)i < cnt)) break;
+    if ((uint32_t)i < cnt) dst[i] = buf[i][tid];
+  }
+  cnt = 0;
 }
 
-// Second pass, one thread per sequence: chunks whose candidate set did not collapse take their entry
-// state from the (now final) exit state of the chunk before them, in order.
-__global__ __launch_bounds__(kThreads) void min_fix(MinArgs a) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// One thread per chunk: proves the chunk's entry state (exactly from the sequence start, or by collapsing
+// the candidate sets during the warm-up), runs the chunk's windows and writes their keys, adjacent
+// duplicates dropped.
+__global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unresolved) {
+  __shared__ uint64_t buf[kBuf][kThreads];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = blockIdx.x * kThreads + tid;
+  ChunkRef c;
+  const bool valid = locate_chunk(a, chunk, &c);
+  const uint8_t* s = a.seq + (valid ? c.base : 0);
+  const uint32_t F = valid ? c.first_window : 0, E = valid ? c.end_window : 0;
+  const uint32_t seq = valid ? c.seq : 0xFFFFFFFFu;
+  const uint32_t slot = valid ? a.wbase[c.seq] : 0;
+  const uint32_t k = a.k, w = a.w, shift = a.key_shift;
+  Machine m;
+  m.reset(k, w);
+  uint32_t i = E;  // next window
+  uint32_t cnt = 0;
+  uint64_t last = ~0ull;
+  bool live = valid, sets = false;
+  uint32_t Mf = 1, Mc = 1;
+  if (valid) {
+    if (F <= kWarm) {  // close to the sequence start: run the windows before the chunk exactly
+      for (uint32_t b = 0; b < w + k - 1; ++b) m.push(base_code(s[b]));
+      m.first_window();
+      if (F == 0) {
+        last = m.key(shift);
+        buf[0][tid] = last;
+        cnt = 1;
+      }
+      i = 1;
+    } else {  // candidates of step j are the positions j-k-1 .. j-1
+      i = F - kWarm;
+      const uint32_t j = i + w - 1;
+      for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(base_code(s[b]));
+      m.j = j;
+      Mf = Mc = (2u << k) - 1u;
+      sets = true;
+    }
+  }
+  for (uint32_t guard = 0; guard < kWarm; ++guard) {
+    if (!__any(sets && (__builtin_popcount(Mf) != 1 || __builtin_popcount(Mc) != 1))) break;
+    if (sets) {
+      m.step_sets(base_code(s[m.j + k - 1]), Mf, Mc);
+      ++i;
+    }
+  }
+  if (sets) {
+    if (__builtin_popcount(Mf) == 1 && __builtin_popcount(Mc) == 1)
+      m.enter(m.j, m.j - 1 - __builtin_ctz(Mf), m.j - 1 - __builtin_ctz(Mc));
+    else
+      live = false;  // left to min_fix
+  }
+
+  auto emit = [&]() {
+    if (i >= F) {
+      const uint64_t key = m.key(shift);
+      if (key != last) {
+        buf[cnt][tid] = key;
+        ++cnt;
+        last = key;
+      }
+    }
+    ++i;
+  };
+  const uint32_t rem = live ? E - i : 0;
+  const uint32_t groups = rem >> 3, tail = rem & 7;
+  const uint32_t max_groups = wave_max_u32(groups), max_tail = wave_max_u32(tail);
+  const uint8_t* next_base = s + (m.j + k - 1);
+  uint64_t word = rem ? load8(next_base) : 0;
+  for (uint32_t g = 0; g < max_groups; ++g) {
+    if (g < groups) {
+      const uint32_t c0 = base_code4((uint32_t)word), c1 = base_code4((uint32_t)(word >> 32));
+      next_base += 8;
+      if (g + 1 < groups || tail) word = load8(next_base);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 3u);
+        emit();
+      }
+    }
+    if (__any(cnt > (uint32_t)(kBuf - 8))) flush_keys(a, buf, tid, seq, slot, cnt);
+  }
+  for (uint32_t u = 0; u < max_tail; ++u) {
+    if (u < tail) {
+      m.step(base_code((uint32_t)(word >> (8 * u)) & 0xFFu));
+      emit();
+    }
+  }
+  if (__any(cnt > 0)) flush_keys(a, buf, tid, seq, slot, cnt);
+  if (valid) {
+    a.exit_f[chunk] = m.pf;
+    a.exit_c[chunk] = m.pc;
+    a.resolved[chunk] = live ? 1 : 0;
+    if (!live) atomicAdd(n_unresolved, 1u);
+  }
+}
+
+// One wave per sequence, only when some chunk's candidate set did not collapse: those chunks take their
+// entry state from the (final) exit state of the chunk before them, in order.  Lane 0 runs the machine.
+__global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n_unresolved) {
+  if (*n_unresolved == 0) return;
+  const uint32_t s = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
   if (s >= a.n) return;
-  for (uint32_t chunk = a.chunk_base[s]; chunk < a.chunk_base[s + 1]; ++chunk) {
-    if (a.resolved[chunk]) continue;
-    ChunkRef c;
-    locate_chunk(a, chunk, &c);
-    uint32_t pf = a.exit_f[chunk - 1], pc = a.exit_c[chunk - 1];
-    a.counts[chunk] = run_chunk<false>(a, c, pf, pc, nullptr);
-    a.exit_f[chunk] = pf;
-    a.exit_c[chunk] = pc;
-    a.resolved[chunk] = 1;
+  const uint32_t c_begin = a.chunk_base[s], c_end = a.chunk_base[s + 1];
+  const uint8_t* seq = a.seq + a.off[s];
+  const uint32_t windows = (uint32_t)(a.off[s + 1] - a.off[s]) - a.w - a.k + 2;
+  const uint32_t k = a.k, w = a.w;
+  uint64_t* out = a.keys + a.wbase[s];
+  for (uint32_t c0 = c_begin; c0 < c_end; c0 += 64) {
+    const uint32_t mine = c0 + lane;
+    uint64_t todo = __ballot(mine < c_end && !a.resolved[mine]);
+    while (todo) {
+      const uint32_t chunk = c0 + (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1;
+      if (lane == 0) {
+        const uint32_t F = (chunk - c_begin) * a.chunk;
+        const uint32_t E = F + a.chunk < windows ? F + a.chunk : windows;
+        Machine m;
+        m.reset(k, w);
+        const uint32_t j = F + w - 1;
+        for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(base_code(seq[b]));
+        m.enter(j, a.exit_f[chunk - 1], a.exit_c[chunk - 1]);
+        uint32_t n_out = a.counter[s];
+        uint64_t last = ~0ull;
+        for (uint32_t i = F; i < E; ++i) {
+          m.step(base_code(seq[m.j + k - 1]));
+          const uint64_t key = m.key(a.key_shift);
+          if (key != last) {
+            out[n_out++] = key;
+            last = key;
+          }
+        }
+        a.counter[s] = n_out;
+        a.exit_f[chunk] = m.pf;
+        a.exit_c[chunk] = m.pc;
+        a.resolved[chunk] = 1;
+      }
+    }
   }
-}
-
-// Third pass: every chunk's entry state is the exit state of its predecessor; write the keys.
-__global__ __launch_bounds__(kThreads) void min_emit(MinArgs a) {
-  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
-  ChunkRef c;
-  if (chunk >= a.max_chunks || !locate_chunk(a, chunk, &c)) return;
-  uint32_t pf = 0, pc = 0;
-  if (c.first_window > 0) {
-    pf = a.exit_f[chunk - 1];
-    pc = a.exit_c[chunk - 1];
-  }
-  run_chunk<true>(a, c, pf, pc, a.keys + a.cand_off[chunk]);
 }
 
 // ---- decimal variant (reference src/minimizer.cpp:124-214), one thread per sequence ----------------
@@ -191,92 +301,162 @@ __device__ uint32_t run_decimal(const MinArgs& a, uint32_t s, uint64_t* out, boo
   return n_out;
 }
 
-__global__ __launch_bounds__(kThreads) void dec_count(MinArgs a) {
+__global__ __launch_bounds__(kThreads) void dec_run(MinArgs a) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= a.max_chunks) return;
-  a.counts[s] = 0;
   if (s >= a.n) return;
   bool bad = false;
-  a.counts[s] = run_decimal<false>(a, s, nullptr, &bad);
+  a.counter[s] = run_decimal<true>(a, s, a.keys + a.wbase[s], &bad);
   if (bad && a.status) atomicMax(a.status, SA_ERR_RANGE);
 }
 
-__global__ __launch_bounds__(kThreads) void dec_emit(MinArgs a) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= a.n) return;
-  bool bad = false;
-  run_decimal<true>(a, s, a.keys + a.cand_off[s], &bad);
-}
-
 // ---- sort / unique / output ---------------------------------------------------------------------
-__global__ void min_segments(const uint32_t* chunk_base, const uint64_t* cand_off, uint32_t n,
-                             uint32_t* seg_begin, uint32_t* seg_end) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  seg_begin[s] = (uint32_t)cand_off[chunk_base[s]];
-  seg_end[s] = (uint32_t)cand_off[chunk_base[s + 1]];
-}
-
-__global__ void min_heads(const uint32_t* seg_begin, const uint32_t* seg_end, uint32_t n, uint8_t* flags) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  if (seg_end[s] > seg_begin[s]) flags[seg_begin[s]] = 2;  // marks a segment start
-}
-
-// flags[i] = 1 where sorted key i starts a run of equal keys inside its sequence's segment
-__global__ void min_flags(const uint64_t* sorted, const uint64_t* cand_off, uint32_t last_chunk,
-                          uint8_t* flags) {
-  const uint64_t total = cand_off[last_chunk];
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total;
-       i += (uint64_t)gridDim.x * blockDim.x)
-    flags[i] = (flags[i] == 2 || sorted[i] != sorted[i - (i ? 1 : 0)] || i == 0) ? 1 : 0;
-}
-
-__global__ void min_zero_tail(const uint64_t* cand_off, uint32_t last_chunk, uint64_t capacity,
-                              uint8_t* flags) {
-  const uint64_t total = cand_off[last_chunk];
-  for (uint64_t i = total + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < capacity;
-       i += (uint64_t)gridDim.x * blockDim.x)
-    flags[i] = 0;
-}
-
-__global__ void min_out_offsets(const uint32_t* seg_begin, const uint64_t* upos, uint32_t n,
-                                const uint64_t* cand_off, uint32_t last_chunk, uint64_t out_capacity,
-                                uint64_t* out_off, int* status) {
+// Sequence s's keys are [wbase[s], wbase[s] + counter[s]) of the key array; the unique pass walks them
+// in tiles of kTile keys.
+__global__ void min_segments(const uint32_t* wbase, const uint32_t* counter, uint32_t n,
+                             uint32_t* seg_begin, uint32_t* seg_end, uint32_t* tiles) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > n) return;
-  const uint64_t total = cand_off[last_chunk];
-  const uint64_t v = (s == n) ? upos[total] : upos[seg_begin[s]];
-  out_off[s] = v;
-  if (s == n && v > out_capacity && status) atomicMax(status, SA_ERR_CAPACITY);
+  if (s == n) {
+    tiles[s] = 0;
+    return;
+  }
+  seg_begin[s] = wbase[s];
+  seg_end[s] = wbase[s] + counter[s];
+  tiles[s] = (counter[s] + kTile - 1) / kTile;
 }
 
-__global__ void min_write(const uint64_t* sorted, const uint8_t* flags, const uint64_t* upos,
-                          const uint64_t* cand_off, uint32_t last_chunk, uint32_t key_shift,
-                          uint64_t out_capacity, uint32_t* out) {
-  const uint64_t total = cand_off[last_chunk];
-  const uint64_t low = (1ull << key_shift) - 1;
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total;
-       i += (uint64_t)gridDim.x * blockDim.x) {
-    if (!flags[i]) continue;
-    const uint64_t o = upos[i];
-    if (o >= out_capacity) continue;
-    const uint64_t key = sorted[i];
-    out[3 * o] = (uint32_t)(key >> key_shift);
-    out[3 * o + 1] = (uint32_t)((key & low) >> 1);
-    out[3 * o + 2] = (uint32_t)(key & 1);
+struct UniqArgs {
+  const uint64_t* sorted;
+  const uint32_t* seg_begin;
+  const uint32_t* seg_end;
+  const uint32_t* tile_base;  // n + 1: first tile of every sequence
+  uint32_t n;
+  uint32_t* tile_count;       // per tile: keys that differ from their predecessor
+  const uint64_t* tile_off;   // exclusive scan of tile_count
+  uint32_t key_shift;
+  uint64_t out_capacity;
+  uint32_t* out;
+  uint64_t* out_off;
+  int* status;
+};
+
+constexpr uint32_t kTileItems = kTile / kThreads;
+
+// Keys [*begin, *end) of the sorted array that form tile `tile`, and the tile's sequence.
+__device__ __forceinline__ uint32_t locate_tile(const UniqArgs& u, uint32_t tile, uint32_t* begin,
+                                                uint32_t* end, uint32_t* seg_first) {
+  uint32_t lo = 0, hi = u.n;  // largest s with tile_base[s] <= tile (sequences without keys own no tile)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (u.tile_base[mid] <= tile)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  *seg_first = u.seg_begin[lo];
+  *begin = u.seg_begin[lo] + (tile - u.tile_base[lo]) * kTile;
+  const uint32_t e = *begin + kTile;
+  *end = e < u.seg_end[lo] ? e : u.seg_end[lo];
+  return lo;
+}
+
+// flags of the thread's kTileItems consecutive keys, packed into a bit mask; keys[] receives them
+__device__ __forceinline__ uint32_t tile_flags(const UniqArgs& u, uint32_t begin, uint32_t end,
+                                               uint32_t seg_first, uint64_t* keys) {
+  const uint32_t first = begin + threadIdx.x * kTileItems;
+  uint64_t prev = (first > seg_first && first < end) ? u.sorted[first - 1] : 0;
+  uint32_t flags = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < kTileItems; ++e) {
+    const uint32_t i = first + e;
+    if (i < end) {
+      keys[e] = u.sorted[i];
+      if (i == seg_first || keys[e] != prev) flags |= 1u << e;
+      prev = keys[e];
+    }
+  }
+  return flags;
+}
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds, uint32_t* excl) {
+  // exclusive prefix of v over the block's threads and the block total
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d);
+    if ((int)lane >= d) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t x = 0; x < kThreads / 64; ++x) {
+    if (x < wave) before += lds[x];
+    total += lds[x];
+  }
+  __syncthreads();
+  *excl = before + inc - v;
+  return total;
+}
+
+__global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
+  __shared__ uint32_t lds[kThreads / 64];
+  const uint32_t tiles = u.tile_base[u.n];
+  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    uint32_t begin, end, seg_first;
+    locate_tile(u, tile, &begin, &end, &seg_first);
+    uint64_t keys[kTileItems];
+    const uint32_t flags = tile_flags(u, begin, end, seg_first, keys);
+    uint32_t excl;
+    const uint32_t total = block_sum(__builtin_popcount(flags), lds, &excl);
+    if (threadIdx.x == 0) u.tile_count[tile] = total;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void uniq_write(UniqArgs u) {
+  __shared__ uint32_t lds[kThreads / 64];
+  const uint32_t tiles = u.tile_base[u.n];
+  const uint64_t low = (1ull << u.key_shift) - 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint64_t total = u.tile_off[tiles];
+    u.out_off[u.n] = total;
+    if (total > u.out_capacity && u.status) atomicMax(u.status, SA_ERR_CAPACITY);
+  }
+  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    uint32_t begin, end, seg_first;
+    const uint32_t s = locate_tile(u, tile, &begin, &end, &seg_first);
+    uint64_t keys[kTileItems];
+    const uint32_t flags = tile_flags(u, begin, end, seg_first, keys);
+    uint32_t excl;
+    block_sum(__builtin_popcount(flags), lds, &excl);
+    const uint64_t tile_first = u.tile_off[tile];
+    if (threadIdx.x == 0 && begin == seg_first) u.out_off[s] = tile_first;
+    uint64_t o = tile_first + excl;
+#pragma unroll
+    for (uint32_t e = 0; e < kTileItems; ++e) {
+      if (!((flags >> e) & 1u)) continue;
+      if (o < u.out_capacity) {
+        u.out[3 * o] = (uint32_t)(keys[e] >> u.key_shift);
+        u.out[3 * o + 1] = (uint32_t)((keys[e] & low) >> 1);
+        u.out[3 * o + 2] = (uint32_t)(keys[e] & 1);
+      }
+      ++o;
+    }
   }
 }
 
 struct MinPlan {
+  uint32_t chunk;       // windows per chunk
   uint32_t max_chunks;
-  uint64_t capacity;  // candidate keys (upper bound: one per window)
+  uint32_t max_tiles;
+  uint64_t capacity;    // candidate keys (upper bound: one per window)
   uint32_t key_shift, end_bit;
-  size_t scan32_tmp, scan64_tmp, flagscan_tmp, sort_tmp;
+  size_t scan32_tmp, scan64_tmp, sort_tmp;
   size_t total_bytes;
   // workspace offsets
-  size_t o_nchunks, o_chunk_base, o_counts, o_exit_f, o_exit_c, o_resolved, o_cand_off, o_keys, o_sorted,
-      o_flags, o_upos, o_seg_begin, o_seg_end, o_tmp;
+  size_t o_nchunks, o_chunk_base, o_windows, o_wbase, o_counter, o_exit_f, o_exit_c, o_resolved, o_keys,
+      o_sorted, o_seg_begin, o_seg_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_tmp;
 };
 
 uint32_t bits_for(uint64_t v) {
@@ -296,20 +476,21 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   const uint64_t span = (uint64_t)k + w - 2;
   pl->capacity = total_len > span * n ? total_len - span * n : 1;  // total windows
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
-  pl->max_chunks = (variant == SA_MIN_BINARY) ? (uint32_t)(total_len / kChunk + n) : n;
+  // enough chunks to occupy the GPU: 1024 windows each, 256 when the batch is small
+  pl->chunk = (total_len / 1024 >= 65536) ? 1024 : 256;
+  pl->max_chunks = (uint32_t)(total_len / pl->chunk + n);
+  pl->max_tiles = (uint32_t)(pl->capacity / kTile + n);
   const uint32_t value_bits = (variant == SA_MIN_BINARY) ? 2 * k : 31;
   pl->key_shift = bits_for(max_len) + 1;
   pl->end_bit = pl->key_shift + value_bits;
   if (pl->end_bit > 64) return SA_ERR_ARGUMENT;
-  const size_t mc = pl->max_chunks + 1;
+  const size_t mc = pl->max_chunks + 1, mt = (size_t)pl->max_tiles + 1;
   // rocprim temporary storage sizes
   uint32_t* d32 = nullptr;
   uint64_t* d64 = nullptr;
-  uint8_t* d8 = nullptr;
-  pl->scan32_tmp = pl->scan64_tmp = pl->flagscan_tmp = pl->sort_tmp = 0;
+  pl->scan32_tmp = pl->scan64_tmp = pl->sort_tmp = 0;
   if (rocprim::exclusive_scan(nullptr, pl->scan32_tmp, d32, d32, 0u, (size_t)n + 1, rocprim::plus<uint32_t>()) != hipSuccess) return SA_ERR_HIP;
-  if (rocprim::exclusive_scan(nullptr, pl->scan64_tmp, d32, d64, (uint64_t)0, mc, rocprim::plus<uint64_t>()) != hipSuccess) return SA_ERR_HIP;
-  if (rocprim::exclusive_scan(nullptr, pl->flagscan_tmp, d8, d64, (uint64_t)0, (size_t)pl->capacity + 1, rocprim::plus<uint64_t>()) != hipSuccess) return SA_ERR_HIP;
+  if (rocprim::exclusive_scan(nullptr, pl->scan64_tmp, d32, d64, (uint64_t)0, mt, rocprim::plus<uint64_t>()) != hipSuccess) return SA_ERR_HIP;
   if (n == 1) {
     if (rocprim::radix_sort_keys(nullptr, pl->sort_tmp, d64, d64, (size_t)pl->capacity, 0u, pl->end_bit) != hipSuccess) return SA_ERR_HIP;
   } else {
@@ -321,20 +502,24 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
     o += round_up(bytes ? bytes : 1, 256);
     return at;
   };
-  pl->o_nchunks = take(((size_t)n + 1) * 4);
-  pl->o_chunk_base = take(((size_t)n + 1) * 4);
-  pl->o_counts = take(mc * 4);
+  const size_t n1 = ((size_t)n + 1) * 4;
+  pl->o_nchunks = take(n1);
+  pl->o_chunk_base = take(n1);
+  pl->o_windows = take(n1);
+  pl->o_wbase = take(n1);
+  pl->o_counter = take(n1);      // n counters + the count of unresolved chunks
   pl->o_exit_f = take(mc * 4);
   pl->o_exit_c = take(mc * 4);
   pl->o_resolved = take(mc);
-  pl->o_cand_off = take(mc * 8);
   pl->o_keys = take((pl->capacity + 1) * 8);
   pl->o_sorted = take((pl->capacity + 1) * 8);
-  pl->o_flags = take(pl->capacity + 2);
-  pl->o_upos = take((pl->capacity + 2) * 8);
-  pl->o_seg_begin = take(((size_t)n + 1) * 4);
-  pl->o_seg_end = take(((size_t)n + 1) * 4);
-  pl->o_tmp = take(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), std::max(pl->flagscan_tmp, pl->sort_tmp)));
+  pl->o_seg_begin = take(n1);
+  pl->o_seg_end = take(n1);
+  pl->o_tiles = take(n1);
+  pl->o_tile_base = take(n1);
+  pl->o_tile_count = take(mt * 4);
+  pl->o_tile_off = take(mt * 8);
+  pl->o_tmp = take(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), pl->sort_tmp));
   pl->total_bytes = o;
   return SA_OK;
 }
@@ -386,13 +571,18 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   char* ws = (char*)d_workspace;
   uint32_t* nchunks = (uint32_t*)(ws + pl.o_nchunks);
   uint32_t* chunk_base = (uint32_t*)(ws + pl.o_chunk_base);
-  uint64_t* cand_off = (uint64_t*)(ws + pl.o_cand_off);
+  uint32_t* windows = (uint32_t*)(ws + pl.o_windows);
+  uint32_t* wbase = (uint32_t*)(ws + pl.o_wbase);
+  uint32_t* counter = (uint32_t*)(ws + pl.o_counter);
+  uint32_t* n_unresolved = counter + b->n;
   uint64_t* keys = (uint64_t*)(ws + pl.o_keys);
   uint64_t* sorted = (uint64_t*)(ws + pl.o_sorted);
-  uint8_t* flags = (uint8_t*)(ws + pl.o_flags);
-  uint64_t* upos = (uint64_t*)(ws + pl.o_upos);
   uint32_t* seg_begin = (uint32_t*)(ws + pl.o_seg_begin);
   uint32_t* seg_end = (uint32_t*)(ws + pl.o_seg_end);
+  uint32_t* tiles = (uint32_t*)(ws + pl.o_tiles);
+  uint32_t* tile_base = (uint32_t*)(ws + pl.o_tile_base);
+  uint32_t* tile_count = (uint32_t*)(ws + pl.o_tile_count);
+  uint64_t* tile_off = (uint64_t*)(ws + pl.o_tile_off);
   void* tmp = ws + pl.o_tmp;
 
   MinArgs a{};
@@ -402,62 +592,72 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.k = b->k;
   a.w = b->w;
   a.key_shift = pl.key_shift;
-  a.max_chunks = pl.max_chunks + 1;  // one trailing empty chunk holds the total after the scan
+  a.chunk = pl.chunk;
   a.chunk_base = chunk_base;
-  a.counts = (uint32_t*)(ws + pl.o_counts);
+  a.wbase = wbase;
+  a.counter = counter;
   a.exit_f = (uint32_t*)(ws + pl.o_exit_f);
   a.exit_c = (uint32_t*)(ws + pl.o_exit_c);
   a.resolved = (uint8_t*)(ws + pl.o_resolved);
-  a.cand_off = cand_off;
   a.keys = keys;
   a.status = b->d_status;
-  const uint32_t last_chunk = pl.max_chunks;
   if (b->d_status) SA_HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), stream));
+  SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 1) * 4, stream));
+  SA_HIP_TRY(hipMemsetAsync(tile_count, 0, ((size_t)pl.max_tiles + 1) * 4, stream));
 
   auto blocks = [](uint64_t items) { return dim3((unsigned)((items + kThreads - 1) / kThreads)); };
-  hipLaunchKernelGGL(min_seq_chunks, blocks(b->n + 1), dim3(kThreads), 0, stream, b->d_off, b->n, b->k,
-                     b->w, b->variant, nchunks);
+  hipLaunchKernelGGL(min_seq_plan, blocks(b->n + 1), dim3(kThreads), 0, stream, b->d_off, b->n, b->k,
+                     b->w, pl.chunk, nchunks, windows);
   size_t t = pl.scan32_tmp;
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, nchunks, chunk_base, 0u, (size_t)b->n + 1,
                                      rocprim::plus<uint32_t>(), stream));
+  t = pl.scan32_tmp;
+  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, windows, wbase, 0u, (size_t)b->n + 1,
+                                     rocprim::plus<uint32_t>(), stream));
   if (b->variant == SA_MIN_BINARY) {
-    hipLaunchKernelGGL(min_count, blocks(a.max_chunks), dim3(kThreads), 0, stream, a);
-    hipLaunchKernelGGL(min_fix, blocks(b->n), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(min_run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
+    hipLaunchKernelGGL(min_fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
   } else {
-    hipLaunchKernelGGL(dec_count, blocks(a.max_chunks), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(dec_run, blocks(b->n), dim3(kThreads), 0, stream, a);
   }
+  hipLaunchKernelGGL(min_segments, blocks(b->n + 1), dim3(kThreads), 0, stream, wbase, counter, b->n,
+                     seg_begin, seg_end, tiles);
   SA_HIP_TRY(hipGetLastError());
-  t = pl.scan64_tmp;
-  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, a.counts, cand_off, (uint64_t)0, (size_t)a.max_chunks,
-                                     rocprim::plus<uint64_t>(), stream));
-  if (b->n == 1)  // keys past the total must sort to the end of the single segment
-    SA_HIP_TRY(hipMemsetAsync(keys, 0xFF, (pl.capacity + 1) * 8, stream));
-  if (b->variant == SA_MIN_BINARY)
-    hipLaunchKernelGGL(min_emit, blocks(a.max_chunks), dim3(kThreads), 0, stream, a);
-  else
-    hipLaunchKernelGGL(dec_emit, blocks(b->n), dim3(kThreads), 0, stream, a);
-  hipLaunchKernelGGL(min_segments, blocks(b->n), dim3(kThreads), 0, stream, chunk_base, cand_off, b->n,
-                     seg_begin, seg_end);
-  SA_HIP_TRY(hipGetLastError());
+  t = pl.scan32_tmp;
+  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tiles, tile_base, 0u, (size_t)b->n + 1,
+                                     rocprim::plus<uint32_t>(), stream));
   t = pl.sort_tmp;
   if (b->n == 1) {
-    SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)pl.capacity, 0u, pl.end_bit, stream));
+    // one long sequence: a device-wide sort of exactly its keys (their number is needed on the host)
+    uint32_t count = 0;
+    SA_HIP_TRY(hipMemcpyAsync(&count, counter, 4, hipMemcpyDeviceToHost, stream));
+    SA_HIP_TRY(hipStreamSynchronize(stream));
+    if (count)
+      SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
   } else {
     SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
                                                   seg_begin, seg_end, 0u, pl.end_bit, stream));
   }
-  SA_HIP_TRY(hipMemsetAsync(flags, 0, pl.capacity + 2, stream));
-  hipLaunchKernelGGL(min_heads, blocks(b->n), dim3(kThreads), 0, stream, seg_begin, seg_end, b->n, flags);
-  const dim3 wide(std::min<uint64_t>((pl.capacity + kThreads - 1) / kThreads, 16384));
-  hipLaunchKernelGGL(min_flags, wide, dim3(kThreads), 0, stream, sorted, cand_off, last_chunk, flags);
+  UniqArgs u{};
+  u.sorted = sorted;
+  u.seg_begin = seg_begin;
+  u.seg_end = seg_end;
+  u.tile_base = tile_base;
+  u.n = b->n;
+  u.tile_count = tile_count;
+  u.tile_off = tile_off;
+  u.key_shift = pl.key_shift;
+  u.out_capacity = b->out_capacity;
+  u.out = b->d_out;
+  u.out_off = b->d_out_off;
+  u.status = b->d_status;
+  const dim3 grid(std::min<uint32_t>(pl.max_tiles, 16384));
+  hipLaunchKernelGGL(uniq_count, grid, dim3(kThreads), 0, stream, u);
   SA_HIP_TRY(hipGetLastError());
-  t = pl.flagscan_tmp;
-  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, flags, upos, (uint64_t)0, (size_t)pl.capacity + 1,
-                                     rocprim::plus<uint64_t>(), stream));
-  hipLaunchKernelGGL(min_out_offsets, blocks(b->n + 1), dim3(kThreads), 0, stream, seg_begin, upos, b->n,
-                     cand_off, last_chunk, b->out_capacity, b->d_out_off, b->d_status);
-  hipLaunchKernelGGL(min_write, wide, dim3(kThreads), 0, stream, sorted, flags, upos, cand_off,
-                     last_chunk, pl.key_shift, b->out_capacity, b->d_out);
+  t = pl.scan64_tmp;
+  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tile_count, tile_off, (uint64_t)0,
+                                     (size_t)pl.max_tiles + 1, rocprim::plus<uint64_t>(), stream));
+  hipLaunchKernelGGL(uniq_write, grid, dim3(kThreads), 0, stream, u);
   SA_HIP_TRY(hipGetLastError());
   return SA_OK;
 }

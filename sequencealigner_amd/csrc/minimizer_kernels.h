@@ -12,13 +12,17 @@
 //     is strictly smaller than the other strand's, else the other strand's (:153-158, 167-172);
 //   * the emitted (value, position, strand) tuples are sorted and de-duplicated (src/utility.cpp:8-26).
 //
-// The state machine is sequential, so a sequence is cut into chunks of kChunk windows, one thread per
+// The state machine is sequential, so a sequence is cut into chunks of `chunk` windows, one thread per
 // chunk.  Invariant (for w <= k + 1): before step j the state lies in [j-k-1, j-1], i.e. at most k+1
-// candidates.  A chunk starts kWarm steps early with ALL candidates (a bit mask of offsets) and steps
-// the whole set; when the set has collapsed to one element before the chunk begins, the chunk's entry
-// state is proven.  Chunks whose sets did not collapse (constant stretches: equal values never merge
-// under a strict compare) are finished by a second kernel that walks them in order from the proven exit
-// state of their predecessor.
+// candidates.  A chunk starts kWarm steps early with ALL candidates (a bit mask of offsets) and steps the
+// whole set until it has collapsed to one element, which proves the chunk's entry state; it then runs as
+// a single state.  Chunks whose sets did not collapse before their first window (constant stretches:
+// equal values never merge under a strict compare) are finished by a second kernel that walks them in
+// order from the exit state of their predecessor.
+//
+// All k-mer values a step can need lie in the last 2k bases, so the history is one 64-bit register pair
+// and every value is a shift and a mask.  The other strand is never materialised: its order is the
+// reverse of the forward order, so its minimum is the forward maximum.
 #ifndef SA_MINIMIZER_KERNELS_H
 #define SA_MINIMIZER_KERNELS_H
 
@@ -26,23 +30,24 @@
 
 namespace sa {
 
-constexpr uint32_t kChunk = 1024;  // windows per chunk
-constexpr uint32_t kWarm = 160;    // warm-up steps in front of a chunk
+constexpr uint32_t kWarm = 160;   // warm-up steps in front of a chunk
+constexpr int kBuf = 16;          // keys a lane can hold in LDS before the wave flushes
+constexpr uint32_t kTile = 2048;  // sorted keys per block in the unique pass
 
 struct MinArgs {
   const uint8_t* seq;
-  const uint64_t* off;        // n + 1 sequence offsets
+  const uint64_t* off;         // n + 1 sequence offsets
   uint32_t n;
   uint32_t k, w;
-  uint32_t key_shift;         // key = value << key_shift | position << 1 | strand
-  uint32_t max_chunks;
-  const uint32_t* chunk_base; // n + 1: first chunk of every sequence
-  uint32_t* counts;           // per chunk: emitted candidates (adjacent duplicates dropped)
-  uint32_t* exit_f;           // per chunk: forward-strand state after the chunk's last window
-  uint32_t* exit_c;           // per chunk: other-strand state
-  uint8_t* resolved;          // per chunk: 1 once counts/exit are final
-  const uint64_t* cand_off;   // per chunk: first slot in keys (exclusive scan of counts)
-  uint64_t* keys;             // candidate keys
+  uint32_t key_shift;          // key = value << key_shift | position << 1 | strand
+  uint32_t chunk;              // windows per chunk (multiple of 8)
+  const uint32_t* chunk_base;  // n + 1: first chunk of every sequence
+  const uint32_t* wbase;       // n + 1: first key slot of every sequence (exclusive scan of its windows)
+  uint32_t* counter;           // n: keys written so far per sequence
+  uint32_t* exit_f;            // per chunk: forward-strand state after the chunk's last window
+  uint32_t* exit_c;            // per chunk: other-strand state
+  uint8_t* resolved;           // per chunk: 1 once its keys are written and its exit state is final
+  uint64_t* keys;              // candidate keys; sequence s owns [wbase[s], wbase[s] + counter[s])
   int* status;
 };
 
@@ -52,101 +57,10 @@ __device__ __forceinline__ uint32_t base_code(uint32_t c) {
   return x ^ ((~x >> 1) & 1u);
 }
 
-// Streams the 2-bit codes of one sequence, keeping the last 64 bases in a 128-bit history.  After
-// advance_to(b) the newest base is b; kmer(x) = V[x] needs x + k - 1 <= b and b - x <= 63 - k.
-struct BaseStream {
-  const uint8_t* s;
-  unsigned __int128 hist;
-  uint64_t next;      // index of the next base to load
-  uint64_t buf;       // the aligned 8 bytes of the blob that contain base `next - 1`
-  uint64_t buf_addr;  // their address (8-byte aligned), ~0 when nothing is buffered
-  uint32_t k;
-  uint32_t mask;
-  __device__ __forceinline__ void init(const uint8_t* seq, uint64_t first, uint32_t k_) {
-    s = seq;
-    next = first;
-    hist = 0;
-    buf = 0;
-    buf_addr = ~0ull;
-    k = k_;
-    mask = (k_ >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k_)) - 1u);
-  }
-  // Bases are fetched 8 at a time with aligned loads (the blob must be 8-byte aligned and readable up
-  // to the next multiple of 8 past its end).
-  __device__ __forceinline__ void advance_to(uint64_t b) {
-    while (next <= b) {
-      const uint64_t addr = (uint64_t)s + next;
-      if ((addr & ~7ull) != buf_addr) {
-        buf_addr = addr & ~7ull;
-        buf = *reinterpret_cast<const uint64_t*>(buf_addr);
-      }
-      hist = (hist << 2) | base_code((uint32_t)(buf >> (8 * (addr & 7))) & 0xFFu);
-      ++next;
-    }
-  }
-  // forward value of the k-mer starting at base x
-  __device__ __forceinline__ uint32_t kmer(uint64_t x) const {
-    const uint32_t sh = 2u * (uint32_t)((next - 1) - (x + k - 1));
-    return (uint32_t)(hist >> sh) & mask;
-  }
-};
-
-// Strand view: forward compares values as they are, the other strand compares mask - value, i.e. the
-// order is reversed.  less(a, b) is "strand value of a < strand value of b" on forward values.
-template <bool FWD>
-__device__ __forceinline__ bool strand_less(uint32_t a, uint32_t b) {
-  return FWD ? (a < b) : (a > b);
-}
-
-// leftmost strict minimum (in strand order) of V[start .. start + w - 1]
-template <bool FWD>
-__device__ __forceinline__ uint32_t leftmost_min(const BaseStream& bs, uint32_t start, uint32_t w,
-                                                 uint32_t* val) {
-  uint32_t p = start, v = bs.kmer(start);
-  for (uint32_t x = start + 1; x < start + w; ++x) {
-    const uint32_t vx = bs.kmer(x);
-    if (strand_less<FWD>(vx, v)) {
-      v = vx;
-      p = x;
-    }
-  }
-  *val = v;
-  return p;
-}
-
-// One step of the state machine for a single state (position p, forward value pv).
-template <bool FWD>
-__device__ __forceinline__ void step_one(const BaseStream& bs, uint32_t j, uint32_t k, uint32_t w,
-                                         uint32_t vj, uint32_t& p, uint32_t& pv) {
-  if (j - k - 1 == p) {  // unsigned arithmetic, as in the reference
-    p = leftmost_min<FWD>(bs, p + 1, w, &pv);
-  } else if (strand_less<FWD>(vj, pv)) {
-    p = j;
-    pv = vj;
-  }
-}
-
-// One step for a SET of candidate states, bit o of M = candidate at position j - 1 - o, o in [0, k].
-template <bool FWD>
-__device__ __forceinline__ uint32_t step_set(const BaseStream& bs, uint32_t j, uint32_t k, uint32_t w,
-                                             uint32_t vj, uint32_t M) {
-  uint32_t out = 0;
-  if ((M >> k) & 1u) {  // the expiring candidate p = j - k - 1
-    uint32_t dummy;
-    const uint32_t p2 = leftmost_min<FWD>(bs, j - k, w, &dummy);
-    out |= 1u << (j - p2);  // offset in the next frame: (j + 1) - 1 - p2
-  }
-  uint32_t rest = M & ((1u << k) - 1u);
-  while (rest) {
-    const uint32_t o = __builtin_ctz(rest);
-    rest &= rest - 1;
-    const uint32_t pv = bs.kmer((uint64_t)j - 1 - o);
-    if (strand_less<FWD>(vj, pv))
-      out |= 1u;  // moves to j
-    else
-      out |= 1u << (o + 1);
-  }
-  return out;
+// The same for 4 bytes at once: byte b of the result is the code of byte b of `c`.
+__device__ __forceinline__ uint32_t base_code4(uint32_t c) {
+  const uint32_t x = (c >> 1) & 0x03030303u;
+  return x ^ ((~x >> 1) & 0x01010101u);
 }
 
 __device__ __forceinline__ uint64_t make_key(uint32_t value, uint32_t pos, uint32_t strand,
@@ -154,11 +68,122 @@ __device__ __forceinline__ uint64_t make_key(uint32_t value, uint32_t pos, uint3
   return ((uint64_t)value << shift) | ((uint64_t)pos << 1) | strand;
 }
 
+// The two-strand state machine of one thread.
+struct Machine {
+  uint32_t lo, hi;          // the last 32 base codes, newest in the low bits of lo
+  uint32_t pf, vf, pc, vc;  // per strand: position of the minimum and its FORWARD value
+  uint32_t j;               // k-mer the next step brings in (the step consumes base j + k - 1)
+  uint32_t k, w, mask;
+
+  __device__ __forceinline__ void reset(uint32_t k_, uint32_t w_) {
+    k = k_;
+    w = w_;
+    mask = (k_ >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k_)) - 1u);
+    lo = hi = 0;
+    pf = pc = vf = vc = j = 0;
+  }
+  __device__ __forceinline__ void push(uint32_t code) {
+    hi = __builtin_amdgcn_alignbit(hi, lo, 30);
+    lo = (lo << 2) | code;
+  }
+  // forward value of the k-mer that starts `back` positions before the newest complete k-mer
+  __device__ __forceinline__ uint32_t value_back(uint32_t back) const {
+    const uint64_t h = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(h >> (2 * back)) & mask;
+  }
+  // Leftmost strict minimum and leftmost strict maximum (= the other strand's minimum) of the w k-mers
+  // that start `back`, `back - 1`, ... positions before the newest one; t* = offsets from the first.
+  __device__ __forceinline__ void scan(uint32_t back, uint32_t* tmin, uint32_t* vmin, uint32_t* tmax,
+                                       uint32_t* vmax) const {
+    uint32_t a = value_back(back), b = a, ta = 0, tb = 0;
+    for (uint32_t t = 1; t < w; ++t) {
+      const uint32_t v = value_back(back - t);
+      if (v < a) {
+        a = v;
+        ta = t;
+      }
+      if (v > b) {
+        b = v;
+        tb = t;
+      }
+    }
+    *tmin = ta;
+    *vmin = a;
+    *tmax = tb;
+    *vmax = b;
+  }
+  // Window 0 (src/minimizer_binary.cpp:149-150) once bases 0 .. w+k-2 have been pushed.
+  __device__ __forceinline__ void first_window() {
+    scan(w - 1, &pf, &vf, &pc, &vc);
+    j = w;
+  }
+  // Enters at step j_ with known positions, once bases up to j_ + k - 2 have been pushed.
+  __device__ __forceinline__ void enter(uint32_t j_, uint32_t pf_, uint32_t pc_) {
+    j = j_;
+    pf = pf_;
+    pc = pc_;
+    vf = value_back(j_ - 1 - pf_);
+    vc = value_back(j_ - 1 - pc_);
+  }
+  // One step (src/minimizer_binary.cpp:112-133 for both strands): consumes base j + k - 1.
+  __device__ __forceinline__ void step(uint32_t code) {
+    push(code);
+    const uint32_t vj = lo & mask;
+    uint32_t tf, rf, tc, rc;
+    scan(k, &tf, &rf, &tc, &rc);  // V[j-k .. j-k+w-1], used by a strand whose minimum expires
+    const uint32_t expiring = j - k - 1;  // unsigned, as in the reference
+    const bool ef = pf == expiring, ec = pc == expiring;
+    const bool lf = vj < vf, lc = vj > vc;
+    pf = ef ? j - k + tf : (lf ? j : pf);
+    vf = ef ? rf : (lf ? vj : vf);
+    pc = ec ? j - k + tc : (lc ? j : pc);
+    vc = ec ? rc : (lc ? vj : vc);
+    ++j;
+  }
+  // The tuple this window emits (src/minimizer_binary.cpp:153-158, 167-172).
+  __device__ __forceinline__ uint64_t key(uint32_t shift) const {
+    const uint32_t cval = mask - vc;
+    const bool f = vf < cval;
+    return make_key(f ? vf : cval, f ? pf : pc, f ? 1u : 0u, shift);
+  }
+
+  // One step for SETS of candidate states: bit o of M = candidate at position j - 1 - o, o in [0, k].
+  __device__ __forceinline__ void step_sets(uint32_t code, uint32_t& Mf, uint32_t& Mc) {
+    push(code);
+    const uint32_t vj = lo & mask;
+    uint32_t tf, rf, tc, rc;
+    scan(k, &tf, &rf, &tc, &rc);
+    const uint32_t low = (1u << k) - 1u;
+    uint32_t of = ((Mf >> k) & 1u) ? 1u << (k - tf) : 0u;  // offset in the next frame: j - (j-k+t)
+    uint32_t oc = ((Mc >> k) & 1u) ? 1u << (k - tc) : 0u;
+    for (uint32_t rest = Mf & low; rest; rest &= rest - 1) {
+      const uint32_t o = __builtin_ctz(rest);
+      of |= (vj < value_back(o + 1)) ? 1u : (2u << o);
+    }
+    for (uint32_t rest = Mc & low; rest; rest &= rest - 1) {
+      const uint32_t o = __builtin_ctz(rest);
+      oc |= (vj > value_back(o + 1)) ? 1u : (2u << o);
+    }
+    Mf = of;
+    Mc = oc;
+    ++j;
+  }
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 struct ChunkRef {
   uint32_t seq;
   uint32_t first_window, end_window;  // windows [first, end) of the sequence
-  uint32_t windows;                   // windows of the whole sequence
   uint64_t base;                      // offset of the sequence in the blob
+  uint32_t len;
 };
 
 __device__ __forceinline__ bool locate_chunk(const MinArgs& a, uint32_t chunk, ChunkRef* r) {
@@ -173,60 +198,12 @@ __device__ __forceinline__ bool locate_chunk(const MinArgs& a, uint32_t chunk, C
   }
   r->seq = lo;
   r->base = a.off[lo];
-  const uint32_t len = (uint32_t)(a.off[lo + 1] - a.off[lo]);
-  r->windows = len - a.w - a.k + 2;
-  r->first_window = (chunk - a.chunk_base[lo]) * kChunk;
-  const uint32_t e = r->first_window + kChunk;
-  r->end_window = e < r->windows ? e : r->windows;
+  r->len = (uint32_t)(a.off[lo + 1] - a.off[lo]);
+  const uint32_t windows = r->len - a.w - a.k + 2;
+  r->first_window = (chunk - a.chunk_base[lo]) * a.chunk;
+  const uint32_t e = r->first_window + a.chunk;
+  r->end_window = e < windows ? e : windows;
   return true;
-}
-
-// Runs windows [first, end) of a sequence from a known state and either counts the candidates or writes
-// their keys.  On entry (pf, pc) is the state AFTER window first - 1 (ignored when first == 0).
-template <bool WRITE>
-__device__ __forceinline__ uint32_t run_chunk(const MinArgs& a, const ChunkRef& c, uint32_t& pf,
-                                              uint32_t& pc, uint64_t* out) {
-  const uint32_t k = a.k, w = a.w;
-  BaseStream bs;
-  uint32_t vf, vc;  // forward values at pf / pc
-  uint32_t i = c.first_window;
-  uint32_t n_out = 0;
-  uint64_t last = ~0ull;
-  auto emit = [&]() {
-    // strictly smaller forward-strand value wins, else the other strand (tie -> other strand)
-    const uint32_t cval = bs.mask - vc;
-    const uint64_t key = (vf < cval) ? make_key(vf, pf, 1, a.key_shift) : make_key(cval, pc, 0, a.key_shift);
-    if (key != last) {
-      if (WRITE) out[n_out] = key;
-      ++n_out;
-      last = key;
-    }
-  };
-  if (i == 0) {
-    bs.init(a.seq + c.base, 0, k);
-    bs.advance_to((uint64_t)w - 1 + k - 1);
-    pf = leftmost_min<true>(bs, 0, w, &vf);
-    pc = leftmost_min<false>(bs, 0, w, &vc);
-    emit();
-    i = 1;
-  } else {
-    // states lie in [j-k-1, j-1] for the first step j = i + w - 1: prime the history from base j-k-1
-    const uint32_t j = i + w - 1;
-    const uint32_t lowest = (j >= k + 1) ? j - k - 1 : 0;
-    bs.init(a.seq + c.base, lowest, k);
-    bs.advance_to((uint64_t)j - 1 + k - 1);
-    vf = bs.kmer(pf);
-    vc = bs.kmer(pc);
-  }
-  for (; i < c.end_window; ++i) {
-    const uint32_t j = i + w - 1;
-    bs.advance_to((uint64_t)j + k - 1);
-    const uint32_t vj = bs.kmer(j);
-    step_one<true>(bs, j, k, w, vj, pf, vf);
-    step_one<false>(bs, j, k, w, vj, pc, vc);
-    emit();
-  }
-  return n_out;
 }
 
 }  // namespace sa

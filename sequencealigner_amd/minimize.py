@@ -36,7 +36,7 @@ class DeviceMinimizeBatch:
         self.total_len = int(off[-1])
         self.max_len, self.min_len = int(lens.max()), int(lens.min())
         self.windows = int((lens - (self.k + self.w - 2)).clip(min=0).sum())
-        # the kernels fetch bases with aligned 8-byte loads: keep 8 bytes of slack behind the blob
+        # the kernels fetch bases with 8-byte loads: keep 8 bytes of slack behind the blob
         self.d_seq = torch.from_numpy(np.concatenate([blob, np.zeros(16, np.uint8)])).to(self.device)
         self.d_off = torch.from_numpy(off.astype(np.uint64).view(np.int64)).to(self.device)
         cap = self.lib.sa_minimize_out_capacity(self.n, self.total_len, self.k, self.w)
