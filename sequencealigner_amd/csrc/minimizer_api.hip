@@ -1,6 +1,7 @@
 // Device-resident batched MinimizeBinary()/Minimize(): planning, kernels and launches.
 #include "minimizer_kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -331,6 +332,7 @@ struct UniqArgs {
   const uint32_t* seg_end;
   const uint32_t* tile_base;  // n + 1: first tile of every sequence
   uint32_t n;
+  uint32_t skip_small;        // uniq_count: tiles of sequences with <= kSmallMax keys are already counted
   uint32_t* tile_count;       // per tile: keys that differ from their predecessor
   const uint64_t* tile_off;   // exclusive scan of tile_count
   uint32_t key_shift;
@@ -400,12 +402,107 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds, uint32_
   return total;
 }
 
+// Sort of one sequence's keys inside LDS, one block per sequence, for sequences with at most kSmallMax
+// keys (one tile): a counting sort on a monotone function of the value groups the keys into bins of a
+// few keys each, then every key finds its rank among the keys of its bin by comparing.  The same
+// comparison tells whether an equal key precedes it, which gives the tile's unique count.
+// Longer sequences are left to the segmented radix sort: big_end[s] = seg_begin[s] hides the sorted ones.
+constexpr uint32_t kSmallMax = kTile;
+constexpr uint32_t kBins = 2048;
+
+// Minimizer values crowd the low end of their range with a long tail, so the bins are spaced like a
+// small floating-point format: 16 octaves below 2^value_bits with 128 bins each; smaller values share bin 0.
+__device__ __forceinline__ uint32_t value_bin(uint32_t v, uint32_t value_bits) {
+  if (value_bits <= 11) return v;
+  const uint32_t lz = __builtin_clz(v | 1u);
+  const int octave = (int)(31 - lz) - (value_bits > 16 ? (int)value_bits - 16 : 0);
+  const uint32_t mant = (lz == 31) ? 0u : ((v << (lz + 1)) >> 25);
+  return octave < 0 ? 0u : (uint32_t)octave * 128u + mant;
+}
+
+__global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uint64_t* sorted,
+                                                       const uint32_t* seg_begin, const uint32_t* seg_end,
+                                                       uint32_t* big_end, const uint32_t* tile_base,
+                                                       uint32_t* tile_count, uint32_t key_shift,
+                                                       uint32_t value_bits) {
+  __shared__ uint64_t grouped[kSmallMax];
+  __shared__ uint64_t ordered[kSmallMax];
+  __shared__ uint32_t bins[kBins];
+  __shared__ uint32_t lds[kThreads / 64];
+  const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  const uint32_t begin = seg_begin[s], count = seg_end[s] - begin;
+  if (count > kSmallMax || count == 0) {
+    if (tid == 0) big_end[s] = seg_end[s];
+    return;
+  }
+  if (tid == 0) big_end[s] = begin;
+  constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
+#pragma unroll
+  for (uint32_t e = 0; e < kBinsPer; ++e) bins[tid + e * kThreads] = 0;
+  __syncthreads();
+  uint64_t mine[kPer];
+  uint32_t bin[kPer];
+#pragma unroll
+  for (uint32_t e = 0; e < kPer; ++e) {
+    const uint32_t i = tid + e * kThreads;
+    if (i < count) {
+      mine[e] = keys[begin + i];
+      bin[e] = value_bin((uint32_t)(mine[e] >> key_shift), value_bits);
+      atomicAdd(&bins[bin[e]], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the bin counts: thread t owns bins t*kBinsPer ..
+  uint32_t local[kBinsPer], sum = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < kBinsPer; ++e) {
+    local[e] = bins[tid * kBinsPer + e];
+    sum += local[e];
+  }
+  uint32_t excl;
+  block_sum(sum, lds, &excl);
+#pragma unroll
+  for (uint32_t e = 0; e < kBinsPer; ++e) {
+    bins[tid * kBinsPer + e] = excl;
+    excl += local[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t e = 0; e < kPer; ++e) {
+    const uint32_t i = tid + e * kThreads;
+    if (i < count) grouped[atomicAdd(&bins[bin[e]], 1u)] = mine[e];
+  }
+  __syncthreads();
+  // bins[b] is now the end of bin b
+  uint32_t uniq = 0;
+  for (uint32_t p = tid; p < count; p += kThreads) {
+    const uint64_t key = grouped[p];
+    const uint32_t b = value_bin((uint32_t)(key >> key_shift), value_bits);
+    const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
+    uint32_t rank = 0;
+    bool dup = false;
+    for (uint32_t m = lo; m < hi; ++m) {
+      const uint64_t other = grouped[m];
+      const bool same_before = other == key && m < p;
+      rank += (other < key || same_before) ? 1u : 0u;
+      dup |= same_before;
+    }
+    ordered[lo + rank] = key;
+    uniq += dup ? 0u : 1u;
+  }
+  uint32_t unused;
+  const uint32_t total = block_sum(uniq, lds, &unused);  // (synchronises the block)
+  for (uint32_t p = tid; p < count; p += kThreads) sorted[begin + p] = ordered[p];
+  if (tid == 0) tile_count[tile_base[s]] = total;
+}
+
 __global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
   __shared__ uint32_t lds[kThreads / 64];
   const uint32_t tiles = u.tile_base[u.n];
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     uint32_t begin, end, seg_first;
-    locate_tile(u, tile, &begin, &end, &seg_first);
+    const uint32_t s = locate_tile(u, tile, &begin, &end, &seg_first);
+    if (u.skip_small && u.seg_end[s] - seg_first <= kTile) continue;
     uint64_t keys[kTileItems];
     const uint32_t flags = tile_flags(u, begin, end, seg_first, keys);
     uint32_t excl;
@@ -456,7 +553,7 @@ struct MinPlan {
   size_t total_bytes;
   // workspace offsets
   size_t o_nchunks, o_chunk_base, o_windows, o_wbase, o_counter, o_exit_f, o_exit_c, o_resolved, o_keys,
-      o_sorted, o_seg_begin, o_seg_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_tmp;
+      o_sorted, o_seg_begin, o_seg_end, o_big_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_tmp;
 };
 
 uint32_t bits_for(uint64_t v) {
@@ -478,6 +575,10 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
   // enough chunks to occupy the GPU: 1024 windows each, 256 when the batch is small
   pl->chunk = (total_len / 1024 >= 65536) ? 1024 : 256;
+  if (const char* e = getenv("SA_MIN_CHUNK")) {  // test hook: any chunk length from 8 to 4096 windows
+    const long v = atol(e);
+    if (v >= 8 && v <= 4096) pl->chunk = (uint32_t)v;
+  }
   pl->max_chunks = (uint32_t)(total_len / pl->chunk + n);
   pl->max_tiles = (uint32_t)(pl->capacity / kTile + n);
   const uint32_t value_bits = (variant == SA_MIN_BINARY) ? 2 * k : 31;
@@ -515,6 +616,7 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_sorted = take((pl->capacity + 1) * 8);
   pl->o_seg_begin = take(n1);
   pl->o_seg_end = take(n1);
+  pl->o_big_end = take(n1);
   pl->o_tiles = take(n1);
   pl->o_tile_base = take(n1);
   pl->o_tile_count = take(mt * 4);
@@ -579,6 +681,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   uint64_t* sorted = (uint64_t*)(ws + pl.o_sorted);
   uint32_t* seg_begin = (uint32_t*)(ws + pl.o_seg_begin);
   uint32_t* seg_end = (uint32_t*)(ws + pl.o_seg_end);
+  uint32_t* big_end = (uint32_t*)(ws + pl.o_big_end);
   uint32_t* tiles = (uint32_t*)(ws + pl.o_tiles);
   uint32_t* tile_base = (uint32_t*)(ws + pl.o_tile_base);
   uint32_t* tile_count = (uint32_t*)(ws + pl.o_tile_count);
@@ -627,6 +730,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tiles, tile_base, 0u, (size_t)b->n + 1,
                                      rocprim::plus<uint32_t>(), stream));
   t = pl.sort_tmp;
+  const bool all_small = b->n > 1 && (uint64_t)b->max_len - (b->k + b->w - 2) <= kSmallMax;
   if (b->n == 1) {
     // one long sequence: a device-wide sort of exactly its keys (their number is needed on the host)
     uint32_t count = 0;
@@ -635,8 +739,12 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     if (count)
       SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
   } else {
-    SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
-                                                  seg_begin, seg_end, 0u, pl.end_bit, stream));
+    hipLaunchKernelGGL(sort_small, dim3(b->n), dim3(kThreads), 0, stream, keys, sorted, seg_begin, seg_end,
+                       big_end, tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift);
+    SA_HIP_TRY(hipGetLastError());
+    if (!all_small)
+      SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
+                                                    seg_begin, big_end, 0u, pl.end_bit, stream));
   }
   UniqArgs u{};
   u.sorted = sorted;
@@ -644,6 +752,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   u.seg_end = seg_end;
   u.tile_base = tile_base;
   u.n = b->n;
+  u.skip_small = b->n > 1;
   u.tile_count = tile_count;
   u.tile_off = tile_off;
   u.key_shift = pl.key_shift;
@@ -652,7 +761,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   u.out_off = b->d_out_off;
   u.status = b->d_status;
   const dim3 grid(std::min<uint32_t>(pl.max_tiles, 16384));
-  hipLaunchKernelGGL(uniq_count, grid, dim3(kThreads), 0, stream, u);
+  if (!all_small) hipLaunchKernelGGL(uniq_count, grid, dim3(kThreads), 0, stream, u);
   SA_HIP_TRY(hipGetLastError());
   t = pl.scan64_tmp;
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tile_count, tile_off, (uint64_t)0,

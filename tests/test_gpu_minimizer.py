@@ -98,3 +98,21 @@ def test_sortedness_and_uniqueness_property():
         key = (r[:, 0].astype(np.uint64) << np.uint64(33)) | (r[:, 1].astype(np.uint64) << np.uint64(1)) | r[:, 2].astype(np.uint64)
         assert (np.diff(key.astype(np.int64)) > 0).all()
         assert r[:, 1].max() <= 10_000 - 15
+
+
+@pytest.mark.parametrize("chunk", ["24", "64", "1024"])
+def test_mixed_lengths_and_chunk_sizes_vs_oracle(oracle, chunk, monkeypatch):
+    """Sequences with more keys than the in-LDS sort takes (left to the segmented sort) next to short
+    ones, constant and periodic stretches that keep the candidate sets from collapsing, and chunk
+    lengths below / equal to / above the warm-up length."""
+    from sequencealigner_amd import minimize, synth
+    monkeypatch.setenv("SA_MIN_CHUNK", chunk)
+    rng = random.Random(5)
+    seqs = [bytes(synth.genome(40_000, seed=81)),
+            bytes(synth.genome(3_000, seed=82)) + b"A" * 5000 + bytes(synth.genome(9_000, seed=83)) + b"CG" * 3000,
+            b"ACGTTGCA" * 2500, b"T" * 30000, bytes(synth.genome(32, seed=84))]
+    seqs += [bytes(synth.genome(rng.randint(32, 12_000), seed=90 + i)) for i in range(40)]
+    for k, w in ((15, 5), (4, 5), (16, 17), (2, 1)):
+        res = minimize.minimize_batch(seqs, k, w)
+        for s, r in zip(seqs, res):
+            assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s), chunk)
