@@ -72,6 +72,7 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint64_t (*buf)[kTh
 // One thread per chunk: proves the chunk's entry state (exactly from the sequence start, or by collapsing
 // the candidate sets during the warm-up), runs the chunk's windows and writes their keys, adjacent
 // duplicates dropped.
+template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unresolved) {
   __shared__ uint64_t buf[kBuf][kThreads];
   const uint32_t tid = threadIdx.x;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   const uint32_t seq = valid ? c.seq : 0xFFFFFFFFu;
   const uint32_t slot = valid ? a.wbase[c.seq] : 0;
   const uint32_t k = a.k, w = a.w, shift = a.key_shift;
-  Machine m;
+  Machine<W> m;
   m.reset(k, w);
   uint32_t i = E;  // next window
   uint32_t cnt = 0;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n
       if (lane == 0) {
         const uint32_t F = (chunk - c_begin) * a.chunk;
         const uint32_t E = F + a.chunk < windows ? F + a.chunk : windows;
-        Machine m;
+        Machine<0> m;
         m.reset(k, w);
         const uint32_t j = F + w - 1;
         for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(base_code(seq[b]));
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
 
 __global__ __launch_bounds__(kThreads) void uniq_write(UniqArgs u) {
   __shared__ uint32_t lds[kThreads / 64];
+  __shared__ uint32_t stage[3 * kTile];
   const uint32_t tiles = u.tile_base[u.n];
   const uint64_t low = (1ull << u.key_shift) - 1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -526,20 +528,25 @@ __global__ __launch_bounds__(kThreads) void uniq_write(UniqArgs u) {
     uint64_t keys[kTileItems];
     const uint32_t flags = tile_flags(u, begin, end, seg_first, keys);
     uint32_t excl;
-    block_sum(__builtin_popcount(flags), lds, &excl);
+    const uint32_t total = block_sum(__builtin_popcount(flags), lds, &excl);
     const uint64_t tile_first = u.tile_off[tile];
     if (threadIdx.x == 0 && begin == seg_first) u.out_off[s] = tile_first;
-    uint64_t o = tile_first + excl;
+    // the tile's triples are gathered in LDS and leave as one contiguous run of dwords
+    uint32_t r = excl;
 #pragma unroll
     for (uint32_t e = 0; e < kTileItems; ++e) {
       if (!((flags >> e) & 1u)) continue;
-      if (o < u.out_capacity) {
-        u.out[3 * o] = (uint32_t)(keys[e] >> u.key_shift);
-        u.out[3 * o + 1] = (uint32_t)((keys[e] & low) >> 1);
-        u.out[3 * o + 2] = (uint32_t)(keys[e] & 1);
-      }
-      ++o;
+      stage[3 * r] = (uint32_t)(keys[e] >> u.key_shift);
+      stage[3 * r + 1] = (uint32_t)((keys[e] & low) >> 1);
+      stage[3 * r + 2] = (uint32_t)(keys[e] & 1);
+      ++r;
     }
+    __syncthreads();
+    const uint64_t room = tile_first < u.out_capacity ? u.out_capacity - tile_first : 0;
+    const uint32_t dwords = 3 * (uint32_t)(total < room ? total : room);
+    uint32_t* dst = u.out + 3 * tile_first;
+    for (uint32_t x = threadIdx.x; x < dwords; x += kThreads) dst[x] = stage[x];
+    __syncthreads();
   }
 }
 
@@ -718,7 +725,8 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, windows, wbase, 0u, (size_t)b->n + 1,
                                      rocprim::plus<uint32_t>(), stream));
   if (b->variant == SA_MIN_BINARY) {
-    hipLaunchKernelGGL(min_run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
+    auto* run = b->w == 5 ? min_run<5> : b->w == 10 ? min_run<10> : min_run<0>;
+    hipLaunchKernelGGL(run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
     hipLaunchKernelGGL(min_fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
   } else {
     hipLaunchKernelGGL(dec_run, blocks(b->n), dim3(kThreads), 0, stream, a);

@@ -68,7 +68,9 @@ __device__ __forceinline__ uint64_t make_key(uint32_t value, uint32_t pos, uint3
   return ((uint64_t)value << shift) | ((uint64_t)pos << 1) | strand;
 }
 
-// The two-strand state machine of one thread.
+// The two-strand state machine of one thread.  W > 0 fixes the window length at compile time (the scan
+// over the window unrolls); W = 0 takes it from reset().
+template <uint32_t W>
 struct Machine {
   uint32_t lo, hi;          // the last 32 base codes, newest in the low bits of lo
   uint32_t pf, vf, pc, vc;  // per strand: position of the minimum and its FORWARD value
@@ -77,7 +79,7 @@ struct Machine {
 
   __device__ __forceinline__ void reset(uint32_t k_, uint32_t w_) {
     k = k_;
-    w = w_;
+    w = W ? W : w_;
     mask = (k_ >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k_)) - 1u);
     lo = hi = 0;
     pf = pc = vf = vc = j = 0;
@@ -96,7 +98,8 @@ struct Machine {
   __device__ __forceinline__ void scan(uint32_t back, uint32_t* tmin, uint32_t* vmin, uint32_t* tmax,
                                        uint32_t* vmax) const {
     uint32_t a = value_back(back), b = a, ta = 0, tb = 0;
-    for (uint32_t t = 1; t < w; ++t) {
+#pragma unroll
+    for (uint32_t t = 1; t < (W ? W : w); ++t) {
       const uint32_t v = value_back(back - t);
       if (v < a) {
         a = v;
