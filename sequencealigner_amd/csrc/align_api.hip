@@ -46,6 +46,8 @@ struct Plan {
   uint64_t qpk_unit_words, tpk_unit_words;
   bool tables;                // packed kernels: the score-table form may be used (mismatch >= gap, bytes)
   uint32_t entry_match, entry_mismatch;
+  int wave_c;                 // wavefront kernels: query columns per lane (8 or 16)
+  bool coop;                  // wavefront kernels: one wave per (pair, strip), all resident
   size_t bytes_per_block;     // workspace bytes per workgroup (4 units)
   uint32_t pairs_per_block;
   const char* name;
@@ -96,17 +98,28 @@ Plan make_plan(const sa_align_batch& b) {
   const bool force_i32 = getenv("SA_FORCE_I32") != nullptr;
   const char* force_family = getenv("SA_FORCE_FAMILY");
   // Long pairs, or too few pairs to fill the lanes of the inter-pair kernels: one pair per wavefront.
-  const bool want_wave = force_family ? !strcmp(force_family, "wave")
-                                      : (max_q > 2048 || max_t > 2048 || (b.n < 2048 && max_q >= 64));
-  // (SA_FORCE_FAMILY=lane|wave is a test hook that pins the choice.)
+  // (Local there needs gap <= 0, mismatch <= 0 and scores below 2^27; other scorings take the general
+  // lane kernel.)  SA_FORCE_FAMILY=lane|wave and SA_FORCE_COOP=0|1 are test hooks that pin the choice.
+  bool want_wave = force_family ? !strcmp(force_family, "wave")
+                                : (max_q > 2048 || max_t > 2048 || (b.n < 2048 && max_q >= 64));
+  if (b.type == SA_LOCAL &&
+      (b.gap > 0 || b.mismatch > 0 ||
+       (long)std::max(b.match, 0) * std::min(max_q, max_t) >= (1L << 27)))
+    want_wave = false;
   if (want_wave) {
+    // Few long pairs: spread every pair's strips over as many wavefronts (narrow strips, all resident).
+    const uint64_t strips8 = (max_q + 511) / 512;
+    const char* force_coop = getenv("SA_FORCE_COOP");
+    pl.coop = b.n * strips8 <= 2048 && (force_coop ? atoi(force_coop) != 0 : (b.n <= 256 && max_q > 1024));
+    pl.wave_c = pl.coop ? 8 : 16;
+    const uint32_t strip = 64 * pl.wave_c;
     pl.family = Family::WaveI32;
-    pl.name = "wave_i32";
-    pl.K = kWaveCols;
-    pl.nstrips = (max_q + kWaveStrip - 1) / kWaveStrip;
+    pl.name = pl.coop ? "wave_i32_coop" : "wave_i32";
+    pl.K = pl.wave_c;
+    pl.nstrips = (max_q + strip - 1) / strip;
     pl.pairs_per_unit = 1;
-    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64;
-    pl.brow_unit_stride = round_up((size_t)max_t + 1, 64) + 64;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 * (pl.wave_c == 16 ? 4 : 2) / 4;
+    pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * (pl.coop ? 2 : 1);
   } else if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
     pl.family = Family::LanePk16;
     pl.name = "lane_pk16";
@@ -142,6 +155,9 @@ Plan make_plan(const sa_align_batch& b) {
                        round_up(units * pl.qpk_unit_words * 4, 256) +
                        round_up(units * pl.tpk_unit_words * 4, 256) +
                        round_up((size_t)pl.pairs_per_block * 4, 256) * 3;
+  if (pl.coop)  // per (pair, strip): progress counter and Local candidate
+    pl.bytes_per_block += round_up((size_t)pl.pairs_per_block * pl.nstrips * 4, 256) +
+                          round_up((size_t)pl.pairs_per_block * pl.nstrips * 12, 256);
   return pl;
 }
 
@@ -226,19 +242,27 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
   return SA_OK;
 }
 
-template <int MODE>
-int launch_wave_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback) {
+template <int MODE, int C, bool COOP>
+int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback) {
   {
     Timed tm(stream, 1);
-    hipLaunchKernelGGL((fill_wave_i32<MODE>), dim3((a.pairs_in_pass + 3) / 4), dim3(kBlock), 0, stream, a);
+    if (COOP) {
+      const size_t cells = (size_t)a.pairs_in_pass * a.nstrips;
+      SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
+      SA_HIP_TRY(hipMemsetAsync(co.progress, 0, cells * 4, stream));
+      SA_HIP_TRY(hipMemsetAsync(co.cand, 0xFF, cells * 12, stream));
+      hipLaunchKernelGGL((fill_wave_i32<MODE, C, true>), dim3((unsigned)cells), dim3(64), 0, stream, a, co);
+      if (MODE == SA_LOCAL)
+        hipLaunchKernelGGL(wave_local_reduce, dim3((a.pairs_in_pass + 63) / 64), dim3(64), 0, stream, a, co);
+    } else {
+      hipLaunchKernelGGL((fill_wave_i32<MODE, C, false>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a, co);
+    }
   }
   SA_HIP_TRY(hipGetLastError());
   if (need_traceback) {
-    WaveI32Layout lay{a.dirs, a.dirs_unit_stride, a.max_t + 64};
     {
       Timed tm(stream, 2);
-      hipLaunchKernelGGL((traceback_kernel<MODE, WaveI32Layout>), dim3((a.pairs_in_pass + 63) / 64),
-                         dim3(64), 0, stream, a, lay);
+      hipLaunchKernelGGL((traceback_wave<MODE, C>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
     }
     SA_HIP_TRY(hipGetLastError());
   }
@@ -246,10 +270,12 @@ int launch_wave_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback)
 }
 
 template <int MODE>
-int launch_pass(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
+int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t* qpk, uint32_t* tpk,
                 const AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
-  if (pl.family == Family::WaveI32) return launch_wave_i32<MODE>(a, stream, need_tb);
+  if (pl.family == Family::WaveI32)
+    return pl.coop ? launch_wave_i32<MODE, 8, true>(a, co, stream, need_tb)
+                   : launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb);
   switch (pl.K) {
     case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, alpha, stream, need_tb);
     case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb);
@@ -340,7 +366,7 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   size_t blocks_per_pass = (workspace_bytes - kFixedWorkspace) / pl.bytes_per_block;
   if (blocks_per_pass > total_blocks) blocks_per_pass = total_blocks;
   const size_t units_per_pass = blocks_per_pass * (kBlock / 64);
-  const size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
+  size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 
   // carve the workspace
   static_assert(sizeof(AlphabetInfo) <= kFixedWorkspace, "fixed workspace too small");
@@ -381,6 +407,19 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   a.end_i = (uint32_t*)w;
   w += round_up(pairs_per_pass * 4, 256);
   a.end_r = (uint32_t*)w;
+  w += round_up(pairs_per_pass * 4, 256);
+  WaveCoop co{};
+  if (pl.coop) {
+    co.ticket = (uint32_t*)d_workspace;  // head of the workspace (the packed kernels keep their table there)
+    co.abort_flag = (int*)d_workspace + 1;
+    co.progress = (uint32_t*)w;
+    w += round_up(pairs_per_pass * pl.nstrips * 4, 256);
+    co.cand = (int32_t*)w;
+    SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
+    // all waves of a pass must be resident at once
+    const size_t cap = std::max<size_t>(1, 2048 / pl.nstrips);
+    if (pairs_per_pass > cap) pairs_per_pass = cap;
+  }
   a.nstrips = pl.nstrips;
   a.score = b->d_score;
   a.target_begin = b->d_target_begin;
@@ -394,12 +433,18 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
     a.pairs_in_pass = (uint32_t)((b->n - base) < pairs_per_pass ? (b->n - base) : pairs_per_pass);
     int rc;
     if (b->type == SA_GLOBAL)
-      rc = launch_pass<SA_GLOBAL>(pl, a, qpk, tpk, alpha, stream, need_tb);
+      rc = launch_pass<SA_GLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb);
     else if (b->type == SA_LOCAL)
-      rc = launch_pass<SA_LOCAL>(pl, a, qpk, tpk, alpha, stream, need_tb);
+      rc = launch_pass<SA_LOCAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb);
     else
-      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, qpk, tpk, alpha, stream, need_tb);
+      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb);
     if (rc) return rc;
+  }
+  if (pl.coop) {  // the cooperative kernels report a wait that ran out through a flag
+    int aborted = 0;
+    SA_HIP_TRY(hipMemcpyAsync(&aborted, co.abort_flag, 4, hipMemcpyDeviceToHost, stream));
+    SA_HIP_TRY(hipStreamSynchronize(stream));
+    if (aborted) return fail(SA_ERR_HIP, "cooperative fill: a strip waited too long for its neighbour");
   }
   return SA_OK;
 }

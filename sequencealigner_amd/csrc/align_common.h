@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void traceback_kernel(AlignArgs a, Layout lay)
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
-    if (MODE == SA_LOCAL && Layout::kImplicitNone && remaining == 0) break;
+    if (MODE == SA_LOCAL && Layout::kImplicitNone && i != 0 && r != 0 && remaining == 0) break;
     const uint32_t d = (i == 0 || r == 0) ? border_dir<MODE>(i, r, a.gap) : lay.get(pl, i, r);
     if (d == DIR_NONE) break;
     uint32_t op;

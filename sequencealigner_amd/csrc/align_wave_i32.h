@@ -1,14 +1,27 @@
-// Intra-pair anti-diagonal ("wavefront") DP fill for long pairs: ONE pair per wavefront, 32-bit scores.
-// The 64 lanes split a strip of 64*16 = 1024 query columns, 16 columns per lane, held in registers; the
-// strip is swept down the target rows with a skew of one row per lane: at step t lane L computes row
-// i = t - L of its 16 columns, so that the cells computed in one step lie on an anti-diagonal of
-// 16-column blocks.  The value a lane needs from its left neighbour (last column of the block to the
-// left, same row) was produced by lane L-1 in the previous step and is passed with a one-lane DPP shift;
-// the diagonal value is the one received the step before.  The right-most column of a strip is handed
-// to the next strip through a per-pair boundary column in memory, read and written 64 rows at a time
-// with coalesced accesses (lane 0 picks its row's value with v_readlane, lane 63's results are gathered
-// into one register, one row per lane).
-// Same recurrence, tie-break and clamping as the reference (src/alignment.cpp:63-85, 176-201, 281-303).
+// Intra-pair anti-diagonal ("wavefront") DP fill for long pairs, 32-bit scores.
+//
+// A strip is 64*C query columns, C per lane, held in registers; it is swept down the target rows with a
+// skew of one row per lane: at step st lane L computes row i = st - L of its C columns, so the cells of
+// one step lie on an anti-diagonal of C-column blocks.  The value a lane needs from its left neighbour
+// (last column of the block to the left, same row) was produced by lane L-1 in the previous step and is
+// passed with a one-lane DPP shift; the diagonal value is the one received the step before.  The
+// right-most column of a strip is handed to the next strip through a boundary column in memory, read
+// and written 64 rows at a time with coalesced accesses.
+//
+// Two ways to run the strips of a pair:
+//   * sequential: one wavefront per pair walks its strips one after the other (many pairs per launch);
+//   * cooperative (COOP): one wavefront per (pair, strip), all resident at once, each strip following
+//     its left neighbour at a distance of about two boundary batches.  A strip publishes the number of
+//     boundary rows it has written (release), the next strip polls that counter (acquire) before it
+//     reads them.  Strip numbers are handed out by a ticket counter in start order, so a waiting wave
+//     only ever waits for waves that already run; every wait is bounded and raises an abort flag.
+//
+// Same recurrence, tie-break and clamping as the reference (src/alignment.cpp:63-85, 176-201, 281-303):
+// m = max(diag + sub, up + gap, left + gap), Diag if m == diag + sub, else Left if m == left + gap, else
+// Up; Local clamps m <= 0 to {0, None}.  Registers hold H + gap, so "up" and "left" candidates need no
+// add and the diagonal candidate adds (sub - gap).  Per cell two flags are stored, "diag candidate != m"
+// and "left candidate != m" (the sign bits of candidate - m, shifted into the direction word); None is
+// not stored: a Local cell is None exactly when its score is 0, which the traceback knows.
 #ifndef SA_ALIGN_WAVE_I32_H
 #define SA_ALIGN_WAVE_I32_H
 
@@ -16,118 +29,196 @@
 
 namespace sa {
 
-constexpr int kWaveCols = 16;                  // query columns per lane
-constexpr int kWaveStrip = 64 * kWaveCols;     // query columns per strip
+template <int C>
+struct WaveWord;
+template <>
+struct WaveWord<16> {
+  using type = uint32_t;
+};
+template <>
+struct WaveWord<8> {
+  using type = uint16_t;
+};
 
-// Direction storage of the wavefront kernel: one dword per (strip, step, lane) = 16 cells x 2 bits,
-//   dword[(s * nsteps + t) * 64 + L],  t = i + L,  field 2 * ((r - 1) % 16)
-// so each step's store is one contiguous 256-byte line.  nsteps = max_t + 64.
+// Direction storage: one word of 2*C bits per (strip, step, lane),
+//   word[(s * nsteps + st) * 64 + L],  st = i + L,  cell k = (r - 1) % C:
+//   bit 2C-1-2k = "diag candidate != m", bit 2C-2-2k = "left candidate != m",
+// so each step's store is one contiguous line.  nsteps = max_t + 64.
+template <int C>
 struct WaveI32Layout {
-  static constexpr bool kImplicitNone = false;
-  const uint32_t* dirs;
-  uint64_t pair_stride;
-  uint32_t nsteps;
-  __device__ __forceinline__ uint32_t get(uint32_t pair_local, uint32_t i, uint32_t r) const {
-    const uint32_t c = r - 1;
-    const uint32_t s = c / kWaveStrip, L = (c % kWaveStrip) / kWaveCols, k = c % kWaveCols;
-    const uint64_t w = ((uint64_t)s * nsteps + (i + L)) * 64 + L;
-    return (dirs[pair_local * pair_stride + w] >> (2 * k)) & 3u;
+  using word_t = typename WaveWord<C>::type;
+  static constexpr uint32_t kStrip = 64 * C;
+  __device__ static __forceinline__ uint32_t decode(uint32_t word, uint32_t k) {
+    const uint32_t two = (word >> (2 * C - 2 - 2 * k)) & 3u;  // (not diag) << 1 | (not left)
+    return !(two & 2u) ? DIR_DIAG : !(two & 1u) ? DIR_LEFT : DIR_UP;
   }
 };
+
+struct WaveCoop {
+  uint32_t* ticket;    // one counter per launch
+  int* abort_flag;     // set when a bounded wait ran out
+  uint32_t* progress;  // [pair][strip]: boundary rows published by the strip
+  int32_t* cand;       // [pair][strip][3]: Local candidates (score, row, column)
+};
+
+constexpr uint32_t kSpinLimit = 1u << 24;
 
 __device__ __forceinline__ int dpp_from_lane_below(int v) {
   // wave_shr:1 - lane L receives lane L-1's value, lane 0 keeps `old` (0)
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void fill_wave_i32(AlignArgs a) {
-  constexpr int C = kWaveCols;
-  const uint32_t lane = threadIdx.x & 63;
-  // wave-uniform by construction; readfirstlane lets the compiler keep them in scalar registers
-  const uint32_t pl = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+__device__ __forceinline__ int max3i(int a, int b, int c) {
+  int r;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// acc << 1 | sign bit of diff
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int diff) {
+  return __builtin_amdgcn_alignbit(acc, (uint32_t)diff, 31);
+}
+
+__device__ __forceinline__ bool coop_wait(const uint32_t* progress, uint32_t need, int* abort_flag) {
+  uint32_t polls = 0;
+  while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(2);
+    ++polls;
+    if (polls >= kSpinLimit ||
+        ((polls & 1023u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+// Local requires gap <= 0 and mismatch <= 0 here (checked on the host): cells of the padding columns
+// beyond the query then never exceed an earlier real cell, so they need no masking.
+template <int MODE, int C, bool COOP>
+__global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
+  using word_t = typename WaveWord<C>::type;
+  constexpr uint32_t STRIP = 64 * C;
+  const uint32_t lane = threadIdx.x;
+  uint32_t pl, s_begin, s_end;  // this wave handles strips [s_begin, s_end) of pair pl
+  if (COOP) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(co.ticket, 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    pl = ticket / a.nstrips;
+    s_begin = ticket % a.nstrips;
+    s_end = s_begin + 1;
+  } else {
+    pl = blockIdx.x;
+    s_begin = 0;
+    s_end = a.nstrips;
+  }
   if (pl >= a.pairs_in_pass) return;
   const uint32_t p = a.pair_base + pl;
   const uint8_t* q = a.q + a.q_off[p];
   const uint8_t* t = a.t + a.t_off[p];
   const uint32_t Q = __builtin_amdgcn_readfirstlane((uint32_t)(a.q_off[p + 1] - a.q_off[p]));
   const uint32_t T = __builtin_amdgcn_readfirstlane((uint32_t)(a.t_off[p + 1] - a.t_off[p]));
-  const int match = a.match, mismatch = a.mismatch, gap = a.gap;
-  uint32_t* dirs = a.dirs + (uint64_t)pl * a.dirs_unit_stride;
-  int32_t* bcol = a.brow + (uint64_t)pl * a.brow_unit_stride;  // H[i][strip's last column], i = 0..T
+  const int gap = a.gap;
+  if (Q == 0 || T == 0) {  // no cells: the result is a border value
+    if (s_begin == 0 && lane == 0) {
+      a.score[p] = (MODE == SA_GLOBAL)  ? (T == 0 ? border_row0<MODE>((int)Q, gap) : border_col0<MODE>((int)T, gap))
+                   : (MODE == SA_LOCAL) ? 0
+                                        : border_row0<MODE>((int)Q, gap);
+      a.end_i[pl] = (MODE == SA_GLOBAL) ? T : 0;
+      a.end_r[pl] = (MODE == SA_LOCAL) ? 0 : Q;
+    }
+    return;
+  }
+  const uint32_t nstrips_p = (Q + STRIP - 1) / STRIP;
+  if (s_end > nstrips_p) s_end = nstrips_p;
+  if (s_begin >= s_end) return;
+  const int em = a.match - gap, ex = a.mismatch - gap;
+  word_t* dirs = reinterpret_cast<word_t*>(a.dirs + (uint64_t)pl * a.dirs_unit_stride);
+  int32_t* bbase = a.brow + (uint64_t)pl * a.brow_unit_stride;
+  const uint64_t bhalf = COOP ? a.brow_unit_stride / 2 : 0;  // two boundary columns, used alternately
   const uint32_t nsteps = a.max_t + 64;
-  const uint32_t nstrips = (Q + kWaveStrip - 1) / kWaveStrip;
 
-  // lane-local best cell (Local) / last-column maximum (Semiglobal) / final score (Global)
-  int best = 0;
+  int best = 0;  // Local: best score; Semiglobal: best last-column score
   uint32_t bi = 0, br = 0;
-  int final_score = (T == 0) ? border_row0<MODE>((int)Q, gap) : border_col0<MODE>((int)T, gap);
-  const uint32_t lastc = Q ? Q - 1 : 0;
-  const uint32_t lane_q = (lastc % kWaveStrip) / C, reg_q = lastc % C;  // where column Q lives
+  int final_score = 0;
+  const uint32_t lastc = Q - 1;
+  const uint32_t lane_q = (lastc % STRIP) / C, reg_q = lastc % C;  // where column Q lives
 
-  for (uint32_t s = 0; s < nstrips; ++s) {
-    const uint32_t c0 = s * kWaveStrip + lane * C;  // this lane's columns are r = c0+1 .. c0+C
-    const bool last_strip = (s + 1 == nstrips);
-    int qc[C], Hrow[C];
+  for (uint32_t s = s_begin; s < s_end; ++s) {
+    const uint32_t c0 = s * STRIP + lane * C;  // this lane's columns are r = c0+1 .. c0+C
+    const bool last_strip = (s + 1 == nstrips_p);
+    const int32_t* bin = bbase + ((s + 1) & 1) * bhalf;  // written by strip s-1
+    int32_t* bout_p = bbase + (s & 1) * bhalf;
+    const uint32_t* prog_in = COOP ? co.progress + (uint64_t)pl * a.nstrips + (s - 1) : nullptr;
+    uint32_t* prog_out = COOP ? co.progress + (uint64_t)pl * a.nstrips + s : nullptr;
+    int qc[C], Hg[C];  // query symbols; H[i-1][column] + gap
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       qc[k] = (c0 + k < Q) ? (int)q[c0 + k] : 512 + k;  // beyond the query: equals no byte
-      Hrow[k] = border_row0<MODE>((int)(c0 + 1 + k), gap);
+      Hg[k] = border_row0<MODE>((int)(c0 + 1 + k), gap) + gap;
     }
-    int ldiag = border_row0<MODE>((int)c0, gap);  // H[i-1][c0] for the lane's first row (H[0][0] = 0)
-    int lastcol = 0;                              // H[i][c0 + C] of the row just computed
-    int bnext = 0, bout = 0;                      // 64 boundary rows in flight (one per lane)
+    int ldiag = border_row0<MODE>((int)c0, gap) + gap;  // H[i-1][c0] + gap for the lane's first row
+    int lastcol = 0;                                    // H[i][c0 + C] + gap of the row just computed
+    int bnext = 0, bout = 0;                            // 64 boundary rows in flight (one per lane)
+    int tc_next = (int)t[0];
     const uint32_t steps = T + 63;
     for (uint32_t st = 1; st <= steps; ++st) {
       const uint32_t j = (st - 1) & 63;
       if (s > 0 && j == 0) {  // rows st .. st+63 of the previous strip's last column
+        if (COOP) {
+          const uint32_t need = st + 63 < T ? st + 63 : T;
+          if (!coop_wait(prog_in, need, co.abort_flag)) return;
+        }
         const uint32_t row = st + lane;
-        // read past this CU's L1: the same rows were read and then overwritten during the previous strip
-        bnext = row <= T ? __hip_atomic_load(&bcol[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        // read past this CU's L1: the location is rewritten every other strip
+        bnext = row <= T ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       }
       int recv = dpp_from_lane_below(lastcol);
       if (lane == 0)
-        recv = (s == 0) ? border_col0<MODE>((int)st, gap) : __builtin_amdgcn_readlane(bnext, j);
+        recv = (s == 0) ? border_col0<MODE>((int)st, gap) + gap : __builtin_amdgcn_readlane(bnext, j);
       const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
       if (st > lane && i <= T) {
-        const int tc = (int)t[i - 1];
+        const int tc = tc_next;
+        if (i < T) tc_next = (int)t[i];
         int diag = ldiag, left = recv;
-        uint32_t word = 0;
+        uint32_t acc = 0, rowkey = 0;
 #pragma unroll
         for (int k = 0; k < C; ++k) {
-          const int up = Hrow[k];
-          const int d = diag + (tc == qc[k] ? match : mismatch);
-          const int u = up + gap;
-          const int l = left + gap;
-          int m = max(max(d, u), l);
-          uint32_t dir = (m == d) ? DIR_DIAG : (m == l) ? DIR_LEFT : DIR_UP;
-          if (MODE == SA_LOCAL) {
-            if (m <= 0) {
-              m = 0;
-              dir = DIR_NONE;
-            }
-            // first strict maximum in row-major order (src/alignment.cpp:203-207): highest score,
-            // then smallest row, then smallest column; a lane meets equal rows in column order.
-            const uint32_t r = c0 + 1 + k;
-            if (r <= Q && (m > best || (m == best && i < bi))) {
-              best = m;
-              bi = i;
-              br = r;
-            }
+          const int up = Hg[k];
+          const int d = diag + (tc == qc[k] ? em : ex);
+          int m = max3i(d, up, left);
+          if (MODE == SA_LOCAL) m = max(m, 0);
+          acc = shift_in_sign(acc, d - m);
+          acc = shift_in_sign(acc, left - m);
+          if (MODE == SA_LOCAL) {  // leftmost maximum of the row: larger score, then smaller k
+            const uint32_t key = ((uint32_t)m << 4) + (uint32_t)(15 - k);
+            rowkey = key > rowkey ? key : rowkey;
           }
           diag = up;
-          Hrow[k] = m;
-          left = m;
-          word |= dir << (2 * k);
+          left = m + gap;
+          Hg[k] = left;
         }
-        dirs[((uint64_t)s * nsteps + st) * 64 + lane] = word;
+        dirs[((uint64_t)s * nsteps + st) * 64 + lane] = (word_t)acc;
         ldiag = recv;
         lastcol = left;
+        if (MODE == SA_LOCAL) {
+          // first strict maximum in row-major order (src/alignment.cpp:203-207): a lane meets its rows
+          // in increasing order, so a later row must be strictly better
+          const int rowbest = (int)(rowkey >> 4);
+          if (rowbest > best) {
+            best = rowbest;
+            bi = i;
+            br = c0 + 16 - (rowkey & 15u);
+          }
+        }
         if (last_strip && lane == lane_q) {
-          int v = Hrow[0];
+          int v = Hg[0];
 #pragma unroll
           for (int k = 1; k < C; ++k)
-            if ((uint32_t)k == reg_q) v = Hrow[k];
+            if ((uint32_t)k == reg_q) v = Hg[k];
+          v -= gap;
           if (MODE == SA_SEMIGLOBAL && v > best) {  // src/alignment.cpp:87-92, rows in increasing order
             best = v;
             bi = i;
@@ -143,7 +234,11 @@ __global__ __launch_bounds__(256) void fill_wave_i32(AlignArgs a) {
         if (lane == slot) bout = v63;
         if (slot == 63 || row == T) {
           const uint32_t base = row - slot;  // first row held in bout
-          if (base + lane <= row) bcol[base + lane] = bout;
+          if (base + lane <= row) bout_p[base + lane] = bout;
+          if (COOP) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(prog_out, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -162,7 +257,17 @@ __global__ __launch_bounds__(256) void fill_wave_i32(AlignArgs a) {
         br = orr;
       }
     }
-  } else if (Q > 0) {
+    if (COOP) {  // one candidate per strip; reduced by wave_local_reduce
+      if (lane == 0) {
+        int32_t* c = co.cand + ((uint64_t)pl * a.nstrips + s_begin) * 3;
+        c[0] = best;
+        c[1] = (int32_t)bi;
+        c[2] = (int32_t)br;
+      }
+      return;
+    }
+  } else {
+    if (s_end != nstrips_p) return;  // only the strip with column Q knows the result
     best = __builtin_amdgcn_readlane(best, lane_q);
     bi = (uint32_t)__builtin_amdgcn_readlane((int)bi, lane_q);
     final_score = __builtin_amdgcn_readlane(final_score, lane_q);
@@ -183,6 +288,141 @@ __global__ __launch_bounds__(256) void fill_wave_i32(AlignArgs a) {
   a.score[p] = score;
   a.end_i[pl] = bi;
   a.end_r[pl] = br;
+}
+
+// Cooperative Local: picks each pair's best cell among its strips' candidates: highest score, then
+// smallest row, then smallest column (the first strict maximum in row-major order).
+__global__ void wave_local_reduce(AlignArgs a, WaveCoop co) {
+  const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= a.pairs_in_pass) return;
+  const uint32_t p = a.pair_base + pl;
+  const uint32_t Q = (uint32_t)(a.q_off[p + 1] - a.q_off[p]), T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
+  if (Q == 0 || T == 0) return;  // written by the fill
+  int best = 0;
+  uint32_t bi = 0, br = 0;
+  for (uint32_t s = 0; s < a.nstrips; ++s) {
+    const int32_t* c = co.cand + ((uint64_t)pl * a.nstrips + s) * 3;
+    const int ob = c[0];
+    const uint32_t oi = (uint32_t)c[1], orr = (uint32_t)c[2];
+    if (ob > best || (ob == best && ob > 0 && (oi < bi || (oi == bi && orr < br)))) {
+      best = ob;
+      bi = oi;
+      br = orr;
+    }
+  }
+  a.score[p] = best;
+  a.end_i[pl] = best ? bi : 0;
+  a.end_r[pl] = best ? br : 0;
+}
+
+// Traceback + run-length encoding for the wavefront layout, one wavefront per pair (same rules as
+// traceback_kernel).  The direction words of 64 consecutive steps of a strip are one contiguous block:
+// the wave copies that block, the strip's query symbols and the target symbols of the rows it spans into
+// LDS and walks inside it; every lane follows the same path, lane 0 writes the runs.
+template <int MODE, int C>
+__global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
+  using word_t = typename WaveWord<C>::type;
+  constexpr uint32_t STRIP = 64 * C;
+  __shared__ __attribute__((aligned(16))) word_t tile[64 * 64];
+  __shared__ uint8_t qs[STRIP];
+  __shared__ uint8_t ts[128];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t pl = blockIdx.x;
+  if (pl >= a.pairs_in_pass) return;
+  const uint32_t p = a.pair_base + pl;
+  const uint8_t* q = a.q + a.q_off[p];
+  const uint8_t* t = a.t + a.t_off[p];
+  const uint32_t Q = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
+  const uint32_t T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
+  const word_t* dirs = reinterpret_cast<const word_t*>(a.dirs + (uint64_t)pl * a.dirs_unit_stride);
+  const uint32_t nsteps = a.max_t + 64;
+  uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
+  uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
+  const bool same = (a.match == a.mismatch);
+  uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
+  uint32_t nruns = 0, cur_op = 4, cur_len = 0;
+  int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
+  uint32_t tile_s = ~0u, tile_lo = 0;  // the tile holds steps [tile_lo, tile_lo + 63] of strip tile_s
+  uint32_t ts_base = 0;                // ts[x] = t[ts_base + x]
+  for (;;) {
+    if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
+    if (MODE == SA_SEMIGLOBAL && r == 0) break;
+    uint32_t d;
+    bool eq = false;
+    if (i == 0 || r == 0) {
+      d = border_dir<MODE>(i, r, a.gap);
+    } else {
+      if (MODE == SA_LOCAL && remaining == 0) break;  // an inner cell with score 0 is None
+      const uint32_t c = r - 1;
+      const uint32_t s = c / STRIP, L = (c % STRIP) / C, k = c % C;
+      const uint32_t st = i + L;
+      if (s != tile_s || st < tile_lo || st > tile_lo + 63) {
+        __syncthreads();
+        tile_lo = st >= 63 ? st - 63 : 0;
+        const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + tile_lo) * 64);
+        uint4* dst = reinterpret_cast<uint4*>(tile);
+        constexpr uint32_t kVec = 64 * 64 * sizeof(word_t) / 16;
+#pragma unroll
+        for (uint32_t x = 0; x < kVec / 64; ++x) dst[x * 64 + lane] = src[x * 64 + lane];
+        if (s != tile_s) {
+#pragma unroll
+          for (uint32_t x = 0; x < C; ++x) {
+            const uint32_t col = s * STRIP + x * 64 + lane;
+            qs[x * 64 + lane] = col < Q ? q[col] : 0;
+          }
+          tile_s = s;
+        }
+        // rows of the tile: i = st' - L' for st' in [tile_lo, tile_lo+63], L' in [0, 63]
+        ts_base = tile_lo >= 64 ? tile_lo - 64 : 0;  // index of row (tile_lo - 63) is tile_lo - 64
+#pragma unroll
+        for (uint32_t x = 0; x < 2; ++x) {
+          const uint32_t idx = ts_base + x * 64 + lane;
+          ts[x * 64 + lane] = idx < T ? t[idx] : 0;
+        }
+        __syncthreads();
+      }
+      d = WaveI32Layout<C>::decode(tile[(st - tile_lo) * 64 + L], k);
+      eq = ts[i - 1 - ts_base] == qs[c % STRIP];
+    }
+    if (d == DIR_NONE) break;
+    uint32_t op;
+    if (d == DIR_DIAG) {
+      op = (same || eq) ? SA_OP_M : SA_OP_X;
+      if (MODE == SA_LOCAL) remaining -= eq ? a.match : a.mismatch;
+      --i;
+      --r;
+    } else if (d == DIR_LEFT) {
+      op = SA_OP_I;
+      if (MODE == SA_LOCAL) remaining -= a.gap;
+      --r;
+    } else {
+      op = SA_OP_D;
+      if (MODE == SA_LOCAL) remaining -= a.gap;
+      --i;
+    }
+    if (op == cur_op) {
+      ++cur_len;
+    } else {
+      if (cur_len) {
+        ++nruns;
+        if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
+      }
+      cur_op = op;
+      cur_len = 1;
+    }
+  }
+  if (lane != 0) return;
+  if (cur_len) {
+    ++nruns;
+    if (slot_end) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
+  }
+  if (a.cigar_nruns) a.cigar_nruns[p] = nruns;
+  if (a.target_begin) {
+    if (MODE == SA_LOCAL)
+      a.target_begin[p] = i;  // row where the traceback stopped (src/alignment.cpp:244-246)
+    else                      // index 1 of the CIGAR text is 'D' only for a leading D-run of 1..9
+      a.target_begin[p] = (cur_len && cur_op == SA_OP_D && cur_len <= 9) ? 3u : 1u;
+  }
 }
 
 }  // namespace sa

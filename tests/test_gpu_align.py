@@ -38,13 +38,19 @@ def _force_family(name):
     """Pins the kernel family the dispatcher may choose ("lane": the inter-pair lane kernels, packed
     16-bit where exact, else 32-bit; "wave": one pair per wavefront); None restores automatic choice."""
     import os
-    if name is None:
-        os.environ.pop("SA_FORCE_FAMILY", None)
-    else:
+    os.environ.pop("SA_FORCE_FAMILY", None)
+    os.environ.pop("SA_FORCE_COOP", None)
+    if name == "coop":      # wavefront kernels, one wave per (pair, strip) wherever the batch allows it
+        os.environ["SA_FORCE_FAMILY"] = "wave"
+        os.environ["SA_FORCE_COOP"] = "1"
+    elif name == "wave":    # wavefront kernels, one wave per pair
+        os.environ["SA_FORCE_FAMILY"] = "wave"
+        os.environ["SA_FORCE_COOP"] = "0"
+    elif name is not None:
         os.environ["SA_FORCE_FAMILY"] = name
 
 
-@pytest.fixture(params=["auto", "lane", "wave"])
+@pytest.fixture(params=["auto", "lane", "wave", "coop"])
 def family(request):
     _force_family(None if request.param == "auto" else request.param)
     yield request.param
@@ -168,8 +174,16 @@ def test_full_size_properties():
     assert ((tb + t_used) <= 300).all()
 
 
-def test_long_pairs_vs_oracle(oracle):
-    """Pairs long enough to need several 1024-column strips and the in-memory boundary column."""
+@pytest.fixture(params=["wave", "coop"])
+def wave_mode(request):
+    _force_family(request.param)
+    yield request.param
+    _force_family(None)
+
+
+def test_long_pairs_vs_oracle(oracle, wave_mode):
+    """Pairs long enough to need several strips and the in-memory boundary column, with one wave per
+    pair and with one wave per (pair, strip)."""
     from sequencealigner_amd import align, synth
     q, t = synth.pairs_semiglobal_long(6, seed=21, read_len=2500, window_len=2800, lead=120)
     pairs = [(bytes(a).decode(), bytes(b).decode()) for a, b in zip(q, t)]
@@ -177,7 +191,7 @@ def test_long_pairs_vs_oracle(oracle):
         cases = _oracle_cases(oracle, pairs, typ, m, x, g)
         assert len(cases) == 6
         b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
-        assert b.kernel_name() == "wave_i32"
+        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" else "wave_i32")
         _run_group(cases)
     # one pair with unequal lengths, crossing a strip boundary exactly (2048 columns) and not (2049)
     for ql in (2048, 2049, 1025):
@@ -185,3 +199,15 @@ def test_long_pairs_vs_oracle(oracle):
         tt = tt[:ql - 37]
         for typ in (0, 1, 2):
             _run_group(_oracle_cases(oracle, [(bytes(qq).decode(), bytes(tt).decode())], typ, 1, -1, -1))
+
+
+def test_cooperative_single_long_pair_vs_oracle(oracle):
+    """One 20 kbp x 19 kbp pair: 40 strips in flight at once, each following its left neighbour."""
+    from sequencealigner_amd import align, synth
+    qq, tt = synth.pair_global_long(20_000, seed=77)
+    q, t = bytes(qq).decode(), bytes(tt[:19_000]).decode()
+    for typ, (m, x, g) in ((0, (1, -1, -1)), (1, (2, -3, -2)), (2, (1, -1, -1))):
+        cases = _oracle_cases(oracle, [(q, t)], typ, m, x, g)
+        b = align.DeviceAlignBatch([q], [t], typ, m, x, g)
+        assert b.kernel_name() == "wave_i32_coop"
+        _run_group(cases)
