@@ -108,17 +108,22 @@ Plan make_plan(const sa_align_batch& b) {
     want_wave = false;
   if (want_wave) {
     // Few long pairs: spread every pair's strips over as many wavefronts (narrow strips, all resident).
-    const uint64_t strips8 = (max_q + 511) / 512;
+    static const int coop_c = [] {  // SA_COOP_C=4|8: columns per lane of the cooperative kernel
+      const char* e = getenv("SA_COOP_C");
+      const int v = e ? atoi(e) : 8;
+      return v == 4 ? 4 : 8;
+    }();
+    const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
     const char* force_coop = getenv("SA_FORCE_COOP");
     pl.coop = b.n * strips8 <= 2048 && (force_coop ? atoi(force_coop) != 0 : (b.n <= 256 && max_q > 1024));
-    pl.wave_c = pl.coop ? 8 : 16;
+    pl.wave_c = pl.coop ? coop_c : 16;
     const uint32_t strip = 64 * pl.wave_c;
     pl.family = Family::WaveI32;
     pl.name = pl.coop ? "wave_i32_coop" : "wave_i32";
     pl.K = pl.wave_c;
     pl.nstrips = (max_q + strip - 1) / strip;
     pl.pairs_per_unit = 1;
-    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 * (pl.wave_c == 16 ? 4 : 2) / 4;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 * (pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
     pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * (pl.coop ? 2 : 1);
   } else if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
     pl.family = Family::LanePk16;
@@ -274,8 +279,9 @@ int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t
                 const AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32)
-    return pl.coop ? launch_wave_i32<MODE, 8, true>(a, co, stream, need_tb)
-                   : launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb);
+    return !pl.coop          ? launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb)
+           : pl.wave_c == 4 ? launch_wave_i32<MODE, 4, true>(a, co, stream, need_tb)
+                            : launch_wave_i32<MODE, 8, true>(a, co, stream, need_tb);
   switch (pl.K) {
     case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, alpha, stream, need_tb);
     case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb);

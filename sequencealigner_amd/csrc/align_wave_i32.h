@@ -27,6 +27,8 @@
 
 #include "align_common.h"
 
+#include <type_traits>
+
 namespace sa {
 
 template <int C>
@@ -38,6 +40,10 @@ struct WaveWord<16> {
 template <>
 struct WaveWord<8> {
   using type = uint16_t;
+};
+template <>
+struct WaveWord<4> {
+  using type = uint8_t;
 };
 
 // Direction storage: one word of 2*C bits per (strip, step, lane),
@@ -134,7 +140,10 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
   const uint32_t nstrips_p = (Q + STRIP - 1) / STRIP;
   if (s_end > nstrips_p) s_end = nstrips_p;
   if (s_begin >= s_end) return;
-  const int em = a.match - gap, ex = a.mismatch - gap;
+  // (sub - gap) for equal / unequal symbols, opaque to the optimiser so that the select is not re-split
+  const int em = __builtin_amdgcn_readfirstlane(a.match - gap);
+  const int ex = __builtin_amdgcn_readfirstlane(a.mismatch - gap);
+  __shared__ uint8_t tring[256];
   word_t* dirs = reinterpret_cast<word_t*>(a.dirs + (uint64_t)pl * a.dirs_unit_stride);
   int32_t* bbase = a.brow + (uint64_t)pl * a.brow_unit_stride;
   const uint64_t bhalf = COOP ? a.brow_unit_stride / 2 : 0;  // two boundary columns, used alternately
@@ -162,26 +171,26 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
     int ldiag = border_row0<MODE>((int)c0, gap) + gap;  // H[i-1][c0] + gap for the lane's first row
     int lastcol = 0;                                    // H[i][c0 + C] + gap of the row just computed
     int bnext = 0, bout = 0;                            // 64 boundary rows in flight (one per lane)
-    int tc_next = (int)t[0];
+    // Target symbols go through a ring in LDS (index = target position & 255), 64 new ones every 64
+    // steps; a lane reads the symbol of its next row one step ahead.  Inside the step loop nothing is
+    // left pending on the memory counter between the 64-step batches: a wait on it would also wait for
+    // the step's own stores.
+    if (lane == 0) tring[0] = t[0];
+    int tc_next = (int)t[0];  // lane 0's first row; the other lanes read theirs from the ring
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above and the query symbols
     const uint32_t steps = T + 63;
-    for (uint32_t st = 1; st <= steps; ++st) {
+    word_t* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
+    // One step.  FULL: every lane has a valid row (64 <= st <= T), nothing is predicated.
+    auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_tag)::value;
       const uint32_t j = (st - 1) & 63;
-      if (s > 0 && j == 0) {  // rows st .. st+63 of the previous strip's last column
-        if (COOP) {
-          const uint32_t need = st + 63 < T ? st + 63 : T;
-          if (!coop_wait(prog_in, need, co.abort_flag)) return;
-        }
-        const uint32_t row = st + lane;
-        // read past this CU's L1: the location is rewritten every other strip
-        bnext = row <= T ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      }
-      int recv = dpp_from_lane_below(lastcol);
-      if (lane == 0)
-        recv = (s == 0) ? border_col0<MODE>((int)st, gap) + gap : __builtin_amdgcn_readlane(bnext, j);
+      const int tc = tc_next;
+      tc_next = (int)tring[(st - lane) & 255u];  // position of row st + 1 - lane
+      const int from_left = dpp_from_lane_below(lastcol);
+      const int first = (s == 0) ? border_col0<MODE>((int)st, gap) + gap : __builtin_amdgcn_readlane(bnext, j);
+      const int recv = lane == 0 ? first : from_left;
       const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
-      if (st > lane && i <= T) {
-        const int tc = tc_next;
-        if (i < T) tc_next = (int)t[i];
+      if (FULL || (st > lane && i <= T)) {
         int diag = ldiag, left = recv;
         uint32_t acc = 0, rowkey = 0;
 #pragma unroll
@@ -200,25 +209,24 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
           left = m + gap;
           Hg[k] = left;
         }
-        dirs[((uint64_t)s * nsteps + st) * 64 + lane] = (word_t)acc;
+        drow[(uint64_t)st * 64] = (word_t)acc;
         ldiag = recv;
         lastcol = left;
         if (MODE == SA_LOCAL) {
           // first strict maximum in row-major order (src/alignment.cpp:203-207): a lane meets its rows
           // in increasing order, so a later row must be strictly better
           const int rowbest = (int)(rowkey >> 4);
-          if (rowbest > best) {
-            best = rowbest;
-            bi = i;
-            br = c0 + 16 - (rowkey & 15u);
-          }
+          const bool better = rowbest > best;
+          best = better ? rowbest : best;
+          bi = better ? i : bi;
+          br = better ? c0 + 16 - (rowkey & 15u) : br;
         }
         if (last_strip && lane == lane_q) {
-          int v = Hg[0];
+          // column Q's register, picked with masks (a dynamic index would move Hg out of registers)
+          uint32_t pick = 0;
 #pragma unroll
-          for (int k = 1; k < C; ++k)
-            if ((uint32_t)k == reg_q) v = Hg[k];
-          v -= gap;
+          for (int k = 0; k < C; ++k) pick |= (uint32_t)Hg[k] & ((uint32_t)k == reg_q ? ~0u : 0u);
+          const int v = (int)pick - gap;
           if (MODE == SA_SEMIGLOBAL && v > best) {  // src/alignment.cpp:87-92, rows in increasing order
             best = v;
             bi = i;
@@ -227,11 +235,11 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
         }
       }
       // lane 63 finished row st - 63 of the strip's last column: collect 64 of them, store coalesced
-      if (!last_strip && st >= 64) {
+      if (!last_strip && (FULL || st >= 64)) {
         const int v63 = __builtin_amdgcn_readlane(lastcol, 63);
         const uint32_t row = st - 63;  // 1 ..
         const uint32_t slot = (row - 1) & 63;
-        if (lane == slot) bout = v63;
+        bout = lane == slot ? v63 : bout;
         if (slot == 63 || row == T) {
           const uint32_t base = row - slot;  // first row held in bout
           if (base + lane <= row) bout_p[base + lane] = bout;
@@ -240,6 +248,28 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
             if (lane == 0) __hip_atomic_store(prog_out, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+      }
+    };
+    for (uint32_t b0 = 1; b0 <= steps; b0 += 64) {  // batches of 64 steps
+      {  // target positions b0 .. b0+63
+        const uint32_t pos = b0 + lane;
+        tring[pos & 255u] = pos < T ? t[pos] : (uint8_t)0;
+      }
+      if (s > 0) {  // rows b0 .. b0+63 of the previous strip's last column
+        if (COOP) {
+          const uint32_t need = b0 + 63 < T ? b0 + 63 : T;
+          if (!coop_wait(prog_in, need, co.abort_flag)) return;
+        }
+        const uint32_t row = b0 + lane;
+        // read past this CU's L1: the location is rewritten every other strip
+        bnext = row <= T ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, so that no step has to wait on it
+      if (b0 >= 64 && b0 + 63 <= T) {
+        for (uint32_t x = 0; x < 64; ++x) step(b0 + x, std::true_type{});
+      } else {
+        const uint32_t e = b0 + 63 < steps ? b0 + 63 : steps;
+        for (uint32_t st = b0; st <= e; ++st) step(st, std::false_type{});
       }
     }
   }
@@ -343,6 +373,9 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
   uint32_t tile_s = ~0u, tile_lo = 0;  // the tile holds steps [tile_lo, tile_lo + 63] of strip tile_s
+  constexpr uint32_t kVecPerLane = 64 * sizeof(word_t) / 16;
+  uint4 pre[kVecPerLane];              // the block below, on its way in
+  uint32_t pre_s = ~0u, pre_lo = 0;
   uint32_t ts_base = 0;                // ts[x] = t[ts_base + x]
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
@@ -356,14 +389,18 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       const uint32_t c = r - 1;
       const uint32_t s = c / STRIP, L = (c % STRIP) / C, k = c % C;
       const uint32_t st = i + L;
-      if (s != tile_s || st < tile_lo || st > tile_lo + 63) {
+      if (s != tile_s || (st & ~63u) != tile_lo) {
         __syncthreads();
-        tile_lo = st >= 63 ? st - 63 : 0;
-        const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + tile_lo) * 64);
+        const uint32_t lo = st & ~63u;
         uint4* dst = reinterpret_cast<uint4*>(tile);
-        constexpr uint32_t kVec = 64 * 64 * sizeof(word_t) / 16;
+        if (s == pre_s && lo == pre_lo) {
 #pragma unroll
-        for (uint32_t x = 0; x < kVec / 64; ++x) dst[x * 64 + lane] = src[x * 64 + lane];
+          for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = pre[x];
+        } else {
+          const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + lo) * 64);
+#pragma unroll
+          for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = src[x * 64 + lane];
+        }
         if (s != tile_s) {
 #pragma unroll
           for (uint32_t x = 0; x < C; ++x) {
@@ -372,12 +409,23 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
           }
           tile_s = s;
         }
-        // rows of the tile: i = st' - L' for st' in [tile_lo, tile_lo+63], L' in [0, 63]
-        ts_base = tile_lo >= 64 ? tile_lo - 64 : 0;  // index of row (tile_lo - 63) is tile_lo - 64
+        tile_lo = lo;
+        // rows of the tile: i = st' - L' for st' in [lo, lo+63], L' in [0, 63]
+        ts_base = lo >= 64 ? lo - 64 : 0;  // index of row (lo - 63) is lo - 64
 #pragma unroll
         for (uint32_t x = 0; x < 2; ++x) {
           const uint32_t idx = ts_base + x * 64 + lane;
           ts[x * 64 + lane] = idx < T ? t[idx] : 0;
+        }
+        // the path leaves a tile downwards: fetch the block below while walking this one
+        if (lo >= 64) {
+          pre_s = s;
+          pre_lo = lo - 64;
+          const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + pre_lo) * 64);
+#pragma unroll
+          for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = src[x * 64 + lane];
+        } else {
+          pre_s = ~0u;
         }
         __syncthreads();
       }
