@@ -124,7 +124,7 @@ Plan make_plan(const sa_align_batch& b) {
     pl.nstrips = (max_q + strip - 1) / strip;
     pl.pairs_per_unit = 1;
     pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 * (pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
-    pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * (pl.coop ? 2 : 1);
+    pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * 2 * (pl.coop ? 2 : 1);  // 64-bit entries
   } else if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
     pl.family = Family::LanePk16;
     pl.name = "lane_pk16";
@@ -160,9 +160,8 @@ Plan make_plan(const sa_align_batch& b) {
                        round_up(units * pl.qpk_unit_words * 4, 256) +
                        round_up(units * pl.tpk_unit_words * 4, 256) +
                        round_up((size_t)pl.pairs_per_block * 4, 256) * 3;
-  if (pl.coop)  // per (pair, strip): progress counter and Local candidate
-    pl.bytes_per_block += round_up((size_t)pl.pairs_per_block * pl.nstrips * 4, 256) +
-                          round_up((size_t)pl.pairs_per_block * pl.nstrips * 12, 256);
+  if (pl.coop)  // per (pair, strip): Local candidate
+    pl.bytes_per_block += round_up((size_t)pl.pairs_per_block * pl.nstrips * 12, 256);
   return pl;
 }
 
@@ -254,7 +253,8 @@ int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, 
     if (COOP) {
       const size_t cells = (size_t)a.pairs_in_pass * a.nstrips;
       SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
-      SA_HIP_TRY(hipMemsetAsync(co.progress, 0, cells * 4, stream));
+      // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
+      SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)a.pairs_in_pass * a.brow_unit_stride * 4, stream));
       SA_HIP_TRY(hipMemsetAsync(co.cand, 0xFF, cells * 12, stream));
       hipLaunchKernelGGL((fill_wave_i32<MODE, C, true>), dim3((unsigned)cells), dim3(64), 0, stream, a, co);
       if (MODE == SA_LOCAL)
@@ -418,8 +418,6 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   if (pl.coop) {
     co.ticket = (uint32_t*)d_workspace;  // head of the workspace (the packed kernels keep their table there)
     co.abort_flag = (int*)d_workspace + 1;
-    co.progress = (uint32_t*)w;
-    w += round_up(pairs_per_pass * pl.nstrips * 4, 256);
     co.cand = (int32_t*)w;
     SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
     // all waves of a pass must be resident at once

@@ -11,10 +11,12 @@
 // Two ways to run the strips of a pair:
 //   * sequential: one wavefront per pair walks its strips one after the other (many pairs per launch);
 //   * cooperative (COOP): one wavefront per (pair, strip), all resident at once, each strip following
-//     its left neighbour at a distance of about two boundary batches.  A strip publishes the number of
-//     boundary rows it has written (release), the next strip polls that counter (acquire) before it
-//     reads them.  Strip numbers are handed out by a ticket counter in start order, so a waiting wave
-//     only ever waits for waves that already run; every wait is bounded and raises an abort flag.
+//     its left neighbour at a distance of about two boundary batches.  A boundary entry is one 64-bit
+//     word {value, tag of the writing strip}, written and read with single device-scope accesses: the
+//     next strip polls the 64 entries of its batch until all carry the expected tag, so the data is its
+//     own ready flag and no fence is needed.  Strip numbers are handed out by a ticket counter in start
+//     order, so a waiting wave only ever waits for waves that already run; every wait is bounded and
+//     raises an abort flag.
 //
 // Same recurrence, tie-break and clamping as the reference (src/alignment.cpp:63-85, 176-201, 281-303):
 // m = max(diag + sub, up + gap, left + gap), Diag if m == diag + sub, else Left if m == left + gap, else
@@ -63,7 +65,6 @@ struct WaveI32Layout {
 struct WaveCoop {
   uint32_t* ticket;    // one counter per launch
   int* abort_flag;     // set when a bounded wait ran out
-  uint32_t* progress;  // [pair][strip]: boundary rows published by the strip
   int32_t* cand;       // [pair][strip][3]: Local candidates (score, row, column)
 };
 
@@ -83,21 +84,6 @@ __device__ __forceinline__ int max3i(int a, int b, int c) {
 // acc << 1 | sign bit of diff
 __device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int diff) {
   return __builtin_amdgcn_alignbit(acc, (uint32_t)diff, 31);
-}
-
-__device__ __forceinline__ bool coop_wait(const uint32_t* progress, uint32_t need, int* abort_flag) {
-  uint32_t polls = 0;
-  while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-    __builtin_amdgcn_s_sleep(2);
-    ++polls;
-    if (polls >= kSpinLimit ||
-        ((polls & 1023u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return true;
 }
 
 // Local requires gap <= 0 and mismatch <= 0 here (checked on the host): cells of the padding columns
@@ -145,8 +131,9 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
   const int ex = __builtin_amdgcn_readfirstlane(a.mismatch - gap);
   __shared__ uint8_t tring[256];
   word_t* dirs = reinterpret_cast<word_t*>(a.dirs + (uint64_t)pl * a.dirs_unit_stride);
-  int32_t* bbase = a.brow + (uint64_t)pl * a.brow_unit_stride;
-  const uint64_t bhalf = COOP ? a.brow_unit_stride / 2 : 0;  // two boundary columns, used alternately
+  // boundary columns: 64-bit entries {H + gap, tag}; COOP uses two of them alternately
+  uint64_t* bbase = reinterpret_cast<uint64_t*>(a.brow + (uint64_t)pl * a.brow_unit_stride);
+  const uint64_t bhalf = COOP ? a.brow_unit_stride / 4 : 0;
   const uint32_t nsteps = a.max_t + 64;
 
   int best = 0;  // Local: best score; Semiglobal: best last-column score
@@ -158,10 +145,8 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
   for (uint32_t s = s_begin; s < s_end; ++s) {
     const uint32_t c0 = s * STRIP + lane * C;  // this lane's columns are r = c0+1 .. c0+C
     const bool last_strip = (s + 1 == nstrips_p);
-    const int32_t* bin = bbase + ((s + 1) & 1) * bhalf;  // written by strip s-1
-    int32_t* bout_p = bbase + (s & 1) * bhalf;
-    const uint32_t* prog_in = COOP ? co.progress + (uint64_t)pl * a.nstrips + (s - 1) : nullptr;
-    uint32_t* prog_out = COOP ? co.progress + (uint64_t)pl * a.nstrips + s : nullptr;
+    const uint64_t* bin = bbase + ((s + 1) & 1) * bhalf;  // written by strip s-1 with tag s
+    uint64_t* bout_p = bbase + (s & 1) * bhalf;           // written here with tag s+1
     int qc[C], Hg[C];  // query symbols; H[i-1][column] + gap
 #pragma unroll
     for (int k = 0; k < C; ++k) {
@@ -242,11 +227,9 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
         bout = lane == slot ? v63 : bout;
         if (slot == 63 || row == T) {
           const uint32_t base = row - slot;  // first row held in bout
-          if (base + lane <= row) bout_p[base + lane] = bout;
-          if (COOP) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_store(prog_out, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          if (base + lane <= row)
+            __hip_atomic_store(&bout_p[base + lane], ((uint64_t)(s + 1) << 32) | (uint32_t)bout,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     };
@@ -256,13 +239,22 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
         tring[pos & 255u] = pos < T ? t[pos] : (uint8_t)0;
       }
       if (s > 0) {  // rows b0 .. b0+63 of the previous strip's last column
-        if (COOP) {
-          const uint32_t need = b0 + 63 < T ? b0 + 63 : T;
-          if (!coop_wait(prog_in, need, co.abort_flag)) return;
-        }
         const uint32_t row = b0 + lane;
-        // read past this CU's L1: the location is rewritten every other strip
-        bnext = row <= T ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const bool want = row <= T;
+        uint64_t e = 0;
+        for (uint32_t polls = 0;; ++polls) {
+          // device-scope load: past this CU's L1 (the location is rewritten every other strip)
+          if (want) e = __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!COOP || __all(!want || (uint32_t)(e >> 32) == s)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (polls >= kSpinLimit ||
+              ((polls & 1023u) == 1023u &&
+               __hip_atomic_load(co.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+          }
+        }
+        bnext = (int)(uint32_t)e;
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, so that no step has to wait on it
       if (b0 >= 64 && b0 + 63 <= T) {
