@@ -373,13 +373,12 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
     uint32_t d;
-    bool eq = false;
     if (i == 0 || r == 0) {
-      d = border_dir<MODE>(i, r, a.gap);
+      d = border_dir<MODE>(i, r, a.gap);  // None, Left or Up
     } else {
       if (MODE == SA_LOCAL && remaining == 0) break;  // an inner cell with score 0 is None
       const uint32_t c = r - 1;
-      const uint32_t s = c / STRIP, L = (c % STRIP) / C, k = c % C;
+      const uint32_t s = c / STRIP, L = (c % STRIP) / C;
       const uint32_t st = i + L;
       if (s != tile_s || (st & ~63u) != tile_lo) {
         __syncthreads();
@@ -421,17 +420,59 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         }
         __syncthreads();
       }
-      d = WaveI32Layout<C>::decode(tile[(st - tile_lo) * 64 + L], k);
-      eq = ts[i - 1 - ts_base] == qs[c % STRIP];
+      // Lane x looks at the cell x steps further along the diagonal, (i - x, r - x): the path follows
+      // the diagonal for as many steps as the leading lanes all find Diag inside this tile.
+      const uint32_t ix = i - lane, rx = r - lane;
+      bool ok = lane < i && lane < r && rx - 1 >= s * STRIP;
+      const uint32_t cx = ok ? rx - 1 : c;
+      const uint32_t Lx = (cx % STRIP) / C, kx = cx % C, stx = (ok ? ix : i) + Lx;
+      ok = ok && stx >= tile_lo;
+      const uint32_t dx = ok ? WaveI32Layout<C>::decode(tile[(stx - tile_lo) * 64 + Lx], kx) : (uint32_t)DIR_NONE;
+      const bool eqx = ok && ts[ix - 1 - ts_base] == qs[cx % STRIP];
+      const uint64_t eqm = __ballot(eqx);
+      bool diag_ok = ok && dx == DIR_DIAG;
+      if (MODE == SA_LOCAL) {  // the score of cell x, were all cells before it diagonal moves
+        const int pe = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(eqm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)eqm, 0u));
+        const int val = remaining - (a.match - a.mismatch) * pe - a.mismatch * (int)lane;
+        diag_ok = diag_ok && val != 0;
+      }
+      const uint64_t dm = __ballot(diag_ok);
+      const uint32_t n = ~dm ? (uint32_t)__builtin_ctzll(~dm) : 64u;  // leading diagonal steps
+      if (n > 0) {
+        const uint64_t in_run = n == 64 ? ~0ull : ((1ull << n) - 1);
+        const uint64_t eqs = same ? in_run : (eqm & in_run);
+        if (MODE == SA_LOCAL) {
+          const int ne = __builtin_popcountll(eqm & in_run);
+          remaining -= a.match * ne + a.mismatch * ((int)n - ne);
+        }
+        i -= n;
+        r -= n;
+        for (uint32_t done = 0; done < n;) {  // maximal runs of equal bits, in path order
+          const uint64_t rest = eqs >> done;
+          const bool m = rest & 1ull;
+          const uint64_t flip = m ? ~rest : rest;
+          uint32_t len = flip ? (uint32_t)__builtin_ctzll(flip) : 64u;
+          if (len > n - done) len = n - done;
+          const uint32_t op = m ? SA_OP_M : SA_OP_X;
+          if (op == cur_op) {
+            cur_len += len;
+          } else {
+            if (cur_len) {
+              ++nruns;
+              if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
+            }
+            cur_op = op;
+            cur_len = len;
+          }
+          done += len;
+        }
+        continue;
+      }
+      d = __builtin_amdgcn_readfirstlane(dx);  // lane 0 holds the current cell
     }
-    if (d == DIR_NONE) break;
+    if (d == DIR_NONE || d == DIR_DIAG) break;  // (an inner Diag cell is handled above: None at score 0)
     uint32_t op;
-    if (d == DIR_DIAG) {
-      op = (same || eq) ? SA_OP_M : SA_OP_X;
-      if (MODE == SA_LOCAL) remaining -= eq ? a.match : a.mismatch;
-      --i;
-      --r;
-    } else if (d == DIR_LEFT) {
+    if (d == DIR_LEFT) {
       op = SA_OP_I;
       if (MODE == SA_LOCAL) remaining -= a.gap;
       --r;
