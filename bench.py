@@ -184,6 +184,20 @@ def main():
                 "frac": cells_per_launch / 4 / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
 
+    # HBM traffic of the fill kernel per launch: from the committed counter passes of this same workload
+    # (tools/profile_round.sh; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, in KiB, FETCH_SIZE doubled for
+    # gfx950's half-counted coalesced reads).  Counters cannot be collected inside this process.
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")
+    if args.workload == "sw_150x300" and n == default_pairs and not args.no_cigar and os.path.exists(pmc_file):
+        try:
+            pmc = json.load(open(pmc_file))
+            k = next(v for name, v in pmc.items() if "fill_lane_pk16<1" in name)
+            roofline["traffic"] = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+            roofline["traffic_unit"] = "bytes per fill launch (profiles/r01_pmc_per_launch.json)"
+            roofline["algorithmic_bytes"] = cells_per_launch / 4
+        except (StopIteration, KeyError, ValueError):
+            pass
+
     out = None
     if world.rank == 0:
         cpu = None
@@ -199,7 +213,7 @@ def main():
             "metric": "GCUPS (DP cell updates/s), batched Align() incl. traceback + CIGAR",
             "value": value, "unit": "GCUPS", "n_gpus": world.size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16x2/int32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16x2",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n} pairs/GPU, query {ql} x target {tl}, "
                                    f"{'Local' if typ == 1 else 'Global'}, match 1 mismatch -1 gap -1, "
