@@ -64,7 +64,10 @@ const char* sa_device_arch(int device);
  * Sequences: one byte per symbol (compared as opaque bytes, like target[i-1]==query[r-1] at
  * src/alignment.cpp:63,176,281); pair p has query d_q[q_off[p] .. q_off[p+1]) and target
  * d_t[t_off[p] .. t_off[p+1]).  All d_* pointers are device pointers on `device`; `stream` is a
- * hipStream_t (NULL = default stream).  The call only enqueues work on the stream.
+ * hipStream_t (NULL = default stream).  d_q and d_t must be readable up to 8 bytes past their last
+ * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except for
+ * batches of few long pairs, which run cooperatively (kernel name "wave_i32_coop") and synchronise the
+ * stream once at the end to read the kernels' abort flag.
  *
  * Outputs (each may be NULL if not wanted, except d_score):
  *   d_score[p]         alignment score
@@ -105,8 +108,8 @@ size_t sa_align_workspace_bytes(const sa_align_batch* batch, size_t* min_bytes);
 int sa_align_batch_device(int device, void* stream, const sa_align_batch* batch, void* d_workspace,
                           size_t workspace_bytes);
 
-/* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32",
- * "wavefront_i32", ...), for logs and profiles. */
+/* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32", "wave_i32",
+ * "wave_i32_coop"), for logs and profiles. */
 const char* sa_align_kernel_name(const sa_align_batch* batch);
 
 /* Kernel timing for benchmarks (no counterpart in the reference).  While enabled, every
