@@ -219,9 +219,9 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
   {
     Timed tm(stream, 0);
     PackArgs pk{a.q, a.q_off, a.t, a.t_off, a.pair_base, a.pairs_in_pass, a.max_q, pl.t_pad,
-                (a.max_q + kPackTile - 1) / kPackTile, qpk, tpk, alpha};
-    hipLaunchKernelGGL(pack_lane_pk16, dim3(pk.q_tiles + (pl.t_pad + kPackTile - 1) / kPackTile, units),
-                       dim3(256), 0, stream, pk);
+                (a.max_q + kPackTile - 1) / kPackTile, (pl.t_pad + kPackTile - 1) / kPackTile, qpk, tpk, alpha};
+    hipLaunchKernelGGL(pack_lane_pk16, dim3((pk.q_tiles + pk.t_tiles + 3) / 4, units), dim3(256), 0, stream,
+                       pk);
   }
   SA_HIP_TRY(hipGetLastError());
   Pk16Args x{qpk, tpk, pl.t_pad, pl.bias, units, alpha, pl.entry_match, pl.entry_mismatch};

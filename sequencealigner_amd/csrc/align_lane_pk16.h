@@ -575,11 +575,13 @@ __global__ void alphabet_table(AlphabetInfo* info) {  // one workgroup of 256 th
   if (b == 0) info->small = total <= 4 ? 1u : 0u;
 }
 
-// Transposes the byte sequences of a pass into the lane-interleaved layout the fill kernel reads (the
-// two forms are described at Pk16Args).  One workgroup per (unit, tile of 256 positions); blockIdx.x
-// first walks the query tiles, then the target tiles.  Sequence bytes are fetched four at a time
-// (unaligned dword loads; the blobs are readable up to the next multiple of 8 past their end).
-constexpr uint32_t kPackTile = 256;
+// Rewrites the byte sequences of a pass in the lane-interleaved layout the fill kernel reads (the two
+// forms are described at Pk16Args).  The layout is [position][lane] and a lane owns its two pairs, so no
+// transposition is needed: one wavefront per (unit, tile of 64 positions); every lane fetches 64 bytes of
+// each of its pairs (8-byte loads; the blobs are readable up to 8 bytes past their end) and the wave
+// writes one 256-byte line per position.  blockIdx.x walks the query tiles first, then the target tiles,
+// four tiles per workgroup.
+constexpr uint32_t kPackTile = 64;
 
 struct PackArgs {
   const uint8_t* q;
@@ -588,60 +590,63 @@ struct PackArgs {
   const uint64_t* t_off;
   uint32_t pair_base, pairs_in_pass;
   uint32_t q_cap, t_cap;     // positions per unit in qpk / tpk
-  uint32_t q_tiles;          // tiles of the query side (the rest of gridDim.x is the target side)
+  uint32_t q_tiles, t_tiles; // tiles of the query side / target side
   uint32_t* qpk;
   uint32_t* tpk;
   const AlphabetInfo* alpha;
 };
 
 __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
-  __shared__ uint8_t tile[128][kPackTile + 4];
   __shared__ uint8_t code[256];
   const bool tables = a.alpha && a.alpha->small;
-  const bool is_query = blockIdx.x < a.q_tiles;
+  if (tables) code[threadIdx.x] = a.alpha->code[threadIdx.x];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.q_tiles + a.t_tiles) return;
+  const bool is_query = tile < a.q_tiles;
   const uint32_t unit = blockIdx.y;
-  const uint32_t t0 = (is_query ? blockIdx.x : blockIdx.x - a.q_tiles) * kPackTile;
+  const uint32_t t0 = (is_query ? tile : tile - a.q_tiles) * kPackTile;
   const uint8_t* seq = is_query ? a.q : a.t;
   const uint64_t* off = is_query ? a.q_off : a.t_off;
   const uint32_t len_cap = is_query ? a.q_cap : a.t_cap;
-  uint32_t* out = is_query ? a.qpk : a.tpk;
-  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (tables) code[threadIdx.x] = a.alpha->code[threadIdx.x];
-  // 0xFF marks "past the end" in the tile (in the tables form real entries are codes 0..3; in the
-  // symbols form the length test below is repeated when writing)
-  for (uint32_t pp = wv; pp < 128; pp += 4) {
-    const uint32_t pl = unit * 128 + pp;
-    uint32_t word = 0;
-    if (pl < a.pairs_in_pass) {
-      const uint64_t b = off[a.pair_base + pl], e = off[a.pair_base + pl + 1];
-      const uint64_t pos = b + t0 + 4 * lane;
-      if (pos < e) word = *reinterpret_cast<const uint32_t*>(seq + pos);
-    }
-    *reinterpret_cast<uint32_t*>(&tile[pp][4 * lane]) = word;
-  }
-  __syncthreads();
-  // lengths of this lane's two pairs, to tell real symbols from the bytes behind a sequence
+  uint32_t* out = (is_query ? a.qpk : a.tpk) + ((uint64_t)unit * len_cap + t0) * 64 + lane;
+  const uint32_t plA = unit * 128 + lane, plB = plA + 64;
+  uint64_t offA = 0, offB = 0;
   uint32_t lenA = 0, lenB = 0;
-  {
-    const uint32_t plA = unit * 128 + lane, plB = plA + 64;
-    if (plA < a.pairs_in_pass) lenA = (uint32_t)(off[a.pair_base + plA + 1] - off[a.pair_base + plA]);
-    if (plB < a.pairs_in_pass) lenB = (uint32_t)(off[a.pair_base + plB + 1] - off[a.pair_base + plB]);
+  if (plA < a.pairs_in_pass) {
+    offA = off[a.pair_base + plA];
+    lenA = (uint32_t)(off[a.pair_base + plA + 1] - offA);
+  }
+  if (plB < a.pairs_in_pass) {
+    offB = off[a.pair_base + plB];
+    lenB = (uint32_t)(off[a.pair_base + plB + 1] - offB);
+  }
+  uint64_t wa[8], wb[8];
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t pos = t0 + 8 * j;
+    wa[j] = pos < lenA ? *reinterpret_cast<const uint64_t*>(seq + offA + pos) : 0;
+    wb[j] = pos < lenB ? *reinterpret_cast<const uint64_t*>(seq + offB + pos) : 0;
   }
   const uint32_t pad = is_query ? kQueryPad : kTargetPad;
-  for (uint32_t c = wv; c < kPackTile; c += 4) {
+#pragma unroll
+  for (uint32_t c = 0; c < kPackTile; ++c) {
     const uint32_t pos = t0 + c;
     if (pos >= len_cap) break;
     const bool inA = pos < lenA, inB = pos < lenB;
-    const uint32_t ba = tile[lane][c], bb = tile[lane + 64][c];
-    const uint64_t at = ((uint64_t)unit * len_cap + pos) * 64 + lane;
+    const uint32_t ba = (uint32_t)(wa[c >> 3] >> (8 * (c & 7))) & 0xFFu;
+    const uint32_t bb = (uint32_t)(wb[c >> 3] >> (8 * (c & 7))) & 0xFFu;
+    uint32_t v;
     if (!tables) {
-      out[at] = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
+      v = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
     } else if (is_query) {
-      out[at] = (inA ? (uint32_t)code[ba] : 0xFFFFu) | ((inB ? (uint32_t)code[bb] : 0xFFFFu) << 16);
+      v = (inA ? (uint32_t)code[ba] : 0xFFFFu) | ((inB ? (uint32_t)code[bb] : 0xFFFFu) << 16);
     } else {
       const uint32_t sa = inA ? (uint32_t)code[ba] : 0x0Cu, sb = inB ? 4u + code[bb] : 0x0Cu;
-      out[at] = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
+      v = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
     }
+    out[(uint64_t)c * 64] = v;
   }
 }
 
