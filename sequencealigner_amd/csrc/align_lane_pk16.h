@@ -516,11 +516,15 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   }
 }
 
-// Marks which byte values occur in the query and target blobs of a batch (grid-stride over bytes).
+// Marks which byte values occur in the query and target blobs of a batch (grid-stride over bytes).  A
+// workgroup collects them in a 256-entry LDS table indexed by the byte itself (plain stores of 1: every
+// writer writes the same value), then ORs the entries that were hit into the global bit set.
 __global__ __launch_bounds__(256) void alphabet_scan(const uint8_t* q, const uint64_t* q_off,
                                                      const uint8_t* t, const uint64_t* t_off, uint32_t n,
                                                      AlphabetInfo* info) {
-  uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  __shared__ uint8_t seen[256];
+  seen[threadIdx.x] = 0;
+  __syncthreads();
   const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
 #pragma unroll
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256) void alphabet_scan(const uint8_t* q, const uin
     const uint8_t* base = which ? t : q;
     const uint64_t b0 = which ? t_off[0] : q_off[0], b1 = which ? t_off[n] : q_off[n];
     // 8 bytes per thread and iteration through aligned loads (the blob is 8-byte aligned and readable
-    // up to the next multiple of 8 past its end)
+    // up to 8 bytes past its end)
     const uint64_t w0 = b0 & ~7ull, w1 = (b1 + 7) & ~7ull;
     for (uint64_t w = w0 + 8 * tid; w < w1; w += 8 * nthreads) {
       const uint64_t word = *reinterpret_cast<const uint64_t*>(base + w);
@@ -536,25 +540,12 @@ __global__ __launch_bounds__(256) void alphabet_scan(const uint8_t* q, const uin
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (!inner && (w + j < b0 || w + j >= b1)) continue;
-        const uint32_t c = (uint32_t)(word >> (8 * j)) & 0xFFu;
-        const uint64_t bit = 1ull << (c & 63);
-        const uint32_t hi = c >> 6;
-        m0 |= hi == 0 ? bit : 0;
-        m1 |= hi == 1 ? bit : 0;
-        m2 |= hi == 2 ? bit : 0;
-        m3 |= hi == 3 ? bit : 0;
+        seen[(uint32_t)(word >> (8 * j)) & 0xFFu] = 1;
       }
     }
   }
-  uint32_t words[8] = {(uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32),
-                       (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)m3, (uint32_t)(m3 >> 32)};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint32_t v = words[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicOr(&info->present[i], v);
-  }
+  __syncthreads();
+  if (seen[threadIdx.x]) atomicOr(&info->present[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
 }
 
 // Numbers the symbols that occur (in increasing byte order) when there are at most four of them.
