@@ -93,7 +93,7 @@ def minimizer_leg(dev, steps, cpu_threads, with_cpu):
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import cpu_checker
             chk = cpu_checker.reference() or cpu_checker.restatement()
-            sample = 2000
+            sample = min(len(seqs), 100_000)
             blob = np.concatenate([np.ascontiguousarray(seqs[:sample]).reshape(sample, -1),
                                    np.zeros((sample, 1), np.uint8)], axis=1)   # NUL-terminated
             off = np.arange(sample, dtype=np.uint64) * np.uint64(blob.shape[1])
@@ -169,10 +169,11 @@ def main():
     cells_per_launch = cells_rank * args.steps / fill_launches
     fill_cups = cells_per_launch / (fill_ms * 1e-3)
     achieved_tops = fill_cups * OPS_PER_CELL[typ] / 1e12
+    peak_tops = PEAK_PK16_TOPS if batch.kernel_name() == "lane_pk16" else PEAK_I32_TOPS
     roofline = {
         "kernel": batch.kernel_name(), "bound": "valu_int", "achieved": achieved_tops,
-        "peak": PEAK_PK16_TOPS, "unit": "Tops/s (integer lane-ops; %d per cell update)" % OPS_PER_CELL[typ],
-        "frac": achieved_tops / PEAK_PK16_TOPS, "traffic": None,
+        "peak": peak_tops, "unit": "Tops/s (integer lane-ops; %d per cell update)" % OPS_PER_CELL[typ],
+        "frac": achieved_tops / peak_tops, "traffic": None,
         "fill_ms_per_launch": fill_ms, "fill_gcups": fill_cups / 1e9,
         "launches_per_step": {"pack": int(cnt[0]) // args.steps, "fill": int(cnt[1]) // args.steps,
                               "traceback": int(cnt[2]) // args.steps},
@@ -203,7 +204,7 @@ def main():
         cpu = None
         sample = args.cpu_sample
         if sample < 0:
-            sample = min(n, 200_000 if args.workload == "sw_150x300" else 300)
+            sample = min(n, 1_000_000 if args.workload == "sw_150x300" else 300)
         if sample > 0 and not world.is_dist:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             cpu, cpu_scores = cpu_baseline(q, t, typ, sample, threads)

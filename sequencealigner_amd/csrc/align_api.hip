@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -97,11 +98,24 @@ Plan make_plan(const sa_align_batch& b) {
   const int K16 = pk16_strip_rows();
   const bool force_i32 = getenv("SA_FORCE_I32") != nullptr;
   const char* force_family = getenv("SA_FORCE_FAMILY");
-  // Long pairs, or too few pairs to fill the lanes of the inter-pair kernels: one pair per wavefront.
+  // The lane kernels put 64 or 128 pairs on a wavefront, the wavefront kernels one pair (or one strip of
+  // a pair): which family fills the GPU better depends on the batch.  Rough throughput estimates (TCUPS,
+  // measured on MI355X) decide; pairs longer than 2048 always take the wavefront kernels.
   // (Local there needs gap <= 0, mismatch <= 0 and scores below 2^27; other scorings take the general
   // lane kernel.)  SA_FORCE_FAMILY=lane|wave and SA_FORCE_COOP=0|1 are test hooks that pin the choice.
-  bool want_wave = force_family ? !strcmp(force_family, "wave")
-                                : (max_q > 2048 || max_t > 2048 || (b.n < 2048 && max_q >= 64));
+  const bool pk16_ok = !force_i32 && lane_pk16_applicable(b, K16, &bias);
+  bool want_wave;
+  if (force_family) {
+    want_wave = !strcmp(force_family, "wave");
+  } else if (max_q > 2048 || max_t > 2048) {
+    want_wave = true;
+  } else {
+    const double waves_lane = std::ceil(b.n / (pk16_ok ? 128.0 : 64.0));
+    const double lane_rate = std::min(waves_lane / 1024.0, 1.0) * (pk16_ok ? 5.3 : 0.9);
+    const double strip_eff = max_q / (std::ceil(max_q / 1024.0) * 1024.0) * max_t / (max_t + 63.0);
+    const double wave_rate = std::min(b.n / 2048.0, 1.0) * 3.0 * strip_eff;
+    want_wave = wave_rate > lane_rate;
+  }
   if (b.type == SA_LOCAL &&
       (b.gap > 0 || b.mismatch > 0 ||
        (long)std::max(b.match, 0) * std::min(max_q, max_t) >= (1L << 27)))
@@ -125,7 +139,7 @@ Plan make_plan(const sa_align_batch& b) {
     pl.pairs_per_unit = 1;
     pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 * (pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
     pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * 2 * (pl.coop ? 2 : 1);  // 64-bit entries
-  } else if (!force_i32 && lane_pk16_applicable(b, K16, &bias)) {
+  } else if (pk16_ok) {
     pl.family = Family::LanePk16;
     pl.name = "lane_pk16";
     pl.K = K16;
