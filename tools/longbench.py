@@ -25,9 +25,15 @@ if which in ("both", "sg"):
     q, t = synth.pairs_semiglobal_long(n, seed=3)
     b = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
     print("semi-global", n, "pairs 10k x 11k kernel", b.kernel_name(), "workspace GB", b.workspace_bytes / 1e9, flush=True)
+    import ctypes as C
+    from sequencealigner_amd import capi
+    lib = capi.lib()
     for it in range(2):
+        lib.sa_align_profile(1)
         torch.cuda.synchronize(); t0 = time.time(); b.run(); torch.cuda.synchronize(); dt = time.time() - t0
-        print("  run %.1f ms  %.1f GCUPS" % (dt * 1e3, b.cells / dt / 1e9), flush=True)
+        ms = (C.c_double * 3)(); cnt = (C.c_uint64 * 3)()
+        lib.sa_align_profile_read(ms, cnt); lib.sa_align_profile(0)
+        print("  run %.1f ms  %.1f GCUPS  (fill %.1f ms, traceback %.1f ms)" % (dt * 1e3, b.cells / dt / 1e9, ms[1], ms[2]), flush=True)
     print("  cigars re-score:", rescore(b, n))
     del b; torch.cuda.empty_cache()
 if which in ("both", "nw"):
