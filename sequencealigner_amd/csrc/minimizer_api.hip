@@ -38,8 +38,9 @@ __device__ __forceinline__ uint64_t load8(const uint8_t* p) {  // any alignment
 // Writes the keys the lanes of a wave hold in LDS to their sequences' key ranges.  Lanes are ordered by
 // chunk, so lanes of one sequence are neighbours: the first lane of each run reserves the run's total
 // with one atomic on the sequence's counter.  Must be called by all lanes of the wave.
-__device__ __forceinline__ void flush_keys(const MinArgs& a, uint64_t (*buf)[kThreads], uint32_t tid,
-                                           uint32_t seq, uint32_t slot, uint32_t& cnt) {
+__device__ __forceinline__ void flush_keys(const MinArgs& a, uint32_t (*bufv)[kThreads],
+                                           uint32_t (*bufp)[kThreads], uint32_t tid, uint32_t seq,
+                                           uint32_t slot, uint32_t& cnt) {
   const uint32_t lane = tid & 63;
   uint32_t inc = cnt;
 #pragma unroll
@@ -64,7 +65,7 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint64_t (*buf)[kTh
   uint64_t* dst = a.keys + slot + base + (excl - run_begin);
   for (int i = 0; i < kBuf; ++i) {
     if (!__any((uint32_t)i < cnt)) break;
-    if ((uint32_t)i < cnt) dst[i] = buf[i][tid];
+    if ((uint32_t)i < cnt) dst[i] = ((uint64_t)bufv[i][tid] << a.key_shift) | bufp[i][tid];
   }
   cnt = 0;
 }
@@ -74,7 +75,8 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint64_t (*buf)[kTh
 // duplicates dropped.
 template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unresolved) {
-  __shared__ uint64_t buf[kBuf][kThreads];
+  __shared__ uint32_t bufv[kBuf][kThreads];  // buffered tuples: value
+  __shared__ uint32_t bufp[kBuf][kThreads];  //                  position << 1 | strand
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = blockIdx.x * kThreads + tid;
   ChunkRef c;
@@ -83,29 +85,37 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   const uint32_t F = valid ? c.first_window : 0, E = valid ? c.end_window : 0;
   const uint32_t seq = valid ? c.seq : 0xFFFFFFFFu;
   const uint32_t slot = valid ? a.wbase[c.seq] : 0;
-  const uint32_t k = a.k, w = a.w, shift = a.key_shift;
+  const uint32_t k = a.k, w = a.w;
   Machine<W> m;
   m.reset(k, w);
   uint32_t i = E;  // next window
   uint32_t cnt = 0;
-  uint64_t last = ~0ull;
+  uint32_t lastv = 0, lastp = ~0u;  // the tuple written last (no real tuple has position bits ~0)
+  auto emit = [&]() __attribute__((always_inline)) {
+    uint32_t v, p2;
+    m.tuple(&v, &p2);
+    if (v != lastv || p2 != lastp) {
+      bufv[cnt][tid] = v;
+      bufp[cnt][tid] = p2;
+      ++cnt;
+      lastv = v;
+      lastp = p2;
+    }
+  };
   bool live = valid, sets = false;
   uint32_t Mf = 1, Mc = 1;
   if (valid) {
     if (F <= kWarm) {  // close to the sequence start: run the windows before the chunk exactly
       for (uint32_t b = 0; b < w + k - 1; ++b) m.push(base_code(s[b]));
       m.first_window();
-      if (F == 0) {
-        last = m.key(shift);
-        buf[0][tid] = last;
-        cnt = 1;
-      }
+      if (F == 0) emit();
       i = 1;
     } else {  // candidates of step j are the positions j-k-1 .. j-1
       i = F - kWarm;
       const uint32_t j = i + w - 1;
       for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(base_code(s[b]));
       m.j = j;
+      m.init_window();
       Mf = Mc = (2u << k) - 1u;
       sets = true;
     }
@@ -123,18 +133,18 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
     else
       live = false;  // left to min_fix
   }
-
-  auto emit = [&]() {
-    if (i >= F) {
-      const uint64_t key = m.key(shift);
-      if (key != last) {
-        buf[cnt][tid] = key;
-        ++cnt;
-        last = key;
+  // single steps until the windows left before the chunk are a multiple of 8: a group of 8 steps below
+  // then lies entirely before the chunk (nothing to emit) or entirely inside it
+  {
+    const uint32_t align = (live && i < F) ? ((F - i) & 7u) : 0;
+    const uint32_t max_align = wave_max_u32(align);
+    for (uint32_t u = 0; u < max_align; ++u) {
+      if (u < align) {
+        m.step(base_code(s[m.j + k - 1]));
+        ++i;
       }
     }
-    ++i;
-  };
+  }
   const uint32_t rem = live ? E - i : 0;
   const uint32_t groups = rem >> 3, tail = rem & 7;
   const uint32_t max_groups = wave_max_u32(groups), max_tail = wave_max_u32(tail);
@@ -145,13 +155,19 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
       const uint32_t c0 = base_code4((uint32_t)word), c1 = base_code4((uint32_t)(word >> 32));
       next_base += 8;
       if (g + 1 < groups || tail) word = load8(next_base);
+      if (i >= F) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 3u);
-        emit();
+        for (int u = 0; u < 8; ++u) {
+          m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 3u);
+          emit();
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 3u);
       }
+      i += 8;
     }
-    if (__any(cnt > (uint32_t)(kBuf - 8))) flush_keys(a, buf, tid, seq, slot, cnt);
+    if (__any(cnt > (uint32_t)(kBuf - 8))) flush_keys(a, bufv, bufp, tid, seq, slot, cnt);
   }
   for (uint32_t u = 0; u < max_tail; ++u) {
     if (u < tail) {
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
       emit();
     }
   }
-  if (__any(cnt > 0)) flush_keys(a, buf, tid, seq, slot, cnt);
+  if (__any(cnt > 0)) flush_keys(a, bufv, bufp, tid, seq, slot, cnt);
   if (valid) {
     a.exit_f[chunk] = m.pf;
     a.exit_c[chunk] = m.pc;

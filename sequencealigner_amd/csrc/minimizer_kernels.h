@@ -76,6 +76,9 @@ struct Machine {
   uint32_t pf, vf, pc, vc;  // per strand: position of the minimum and its FORWARD value
   uint32_t j;               // k-mer the next step brings in (the step consumes base j + k - 1)
   uint32_t k, w, mask;
+  // W > 0: the w k-mers an expiring minimum is re-searched in, V[j-1-k .. j-1-k+w-1] after step j-1; each
+  // step drops the oldest and extracts one new value instead of all w
+  uint32_t win[W ? W : 1];
 
   __device__ __forceinline__ void reset(uint32_t k_, uint32_t w_) {
     k = k_;
@@ -115,10 +118,46 @@ struct Machine {
     *tmax = tb;
     *vmax = b;
   }
+  // (Re)builds win[] from the history; the newest complete k-mer must be j - 1.
+  __device__ __forceinline__ void init_window() {
+#pragma unroll
+    for (uint32_t t = 0; t < W; ++t) win[t] = value_back(k - t);
+  }
+  // Pushes base j + k - 1 and finds the re-search result of step j: leftmost strict minimum / maximum of
+  // V[j-k .. j-k+w-1] as offsets from j-k.
+  __device__ __forceinline__ void advance(uint32_t code, uint32_t* tmin, uint32_t* vmin, uint32_t* tmax,
+                                          uint32_t* vmax) {
+    push(code);
+    if (W == 0) {
+      scan(k, tmin, vmin, tmax, vmax);
+      return;
+    }
+#pragma unroll
+    for (uint32_t t = 0; t + 1 < W; ++t) win[t] = win[t + 1];
+    win[W ? W - 1 : 0] = value_back(k - (W - 1));
+    uint32_t a = win[0], b = a, ta = 0, tb = 0;
+#pragma unroll
+    for (uint32_t t = 1; t < W; ++t) {
+      const uint32_t v = win[t];
+      if (v < a) {
+        a = v;
+        ta = t;
+      }
+      if (v > b) {
+        b = v;
+        tb = t;
+      }
+    }
+    *tmin = ta;
+    *vmin = a;
+    *tmax = tb;
+    *vmax = b;
+  }
   // Window 0 (src/minimizer_binary.cpp:149-150) once bases 0 .. w+k-2 have been pushed.
   __device__ __forceinline__ void first_window() {
     scan(w - 1, &pf, &vf, &pc, &vc);
     j = w;
+    init_window();
   }
   // Enters at step j_ with known positions, once bases up to j_ + k - 2 have been pushed.
   __device__ __forceinline__ void enter(uint32_t j_, uint32_t pf_, uint32_t pc_) {
@@ -127,13 +166,13 @@ struct Machine {
     pc = pc_;
     vf = value_back(j_ - 1 - pf_);
     vc = value_back(j_ - 1 - pc_);
+    init_window();
   }
   // One step (src/minimizer_binary.cpp:112-133 for both strands): consumes base j + k - 1.
   __device__ __forceinline__ void step(uint32_t code) {
-    push(code);
-    const uint32_t vj = lo & mask;
     uint32_t tf, rf, tc, rc;
-    scan(k, &tf, &rf, &tc, &rc);  // V[j-k .. j-k+w-1], used by a strand whose minimum expires
+    advance(code, &tf, &rf, &tc, &rc);  // V[j-k .. j-k+w-1], used by a strand whose minimum expires
+    const uint32_t vj = lo & mask;
     const uint32_t expiring = j - k - 1;  // unsigned, as in the reference
     const bool ef = pf == expiring, ec = pc == expiring;
     const bool lf = vj < vf, lc = vj > vc;
@@ -143,19 +182,25 @@ struct Machine {
     vc = ec ? rc : (lc ? vj : vc);
     ++j;
   }
-  // The tuple this window emits (src/minimizer_binary.cpp:153-158, 167-172).
-  __device__ __forceinline__ uint64_t key(uint32_t shift) const {
+  // The tuple this window emits (src/minimizer_binary.cpp:153-158, 167-172): its value and
+  // position << 1 | strand.
+  __device__ __forceinline__ void tuple(uint32_t* value, uint32_t* pos2) const {
     const uint32_t cval = mask - vc;
     const bool f = vf < cval;
-    return make_key(f ? vf : cval, f ? pf : pc, f ? 1u : 0u, shift);
+    *value = f ? vf : cval;
+    *pos2 = f ? (pf << 1 | 1u) : (pc << 1);
+  }
+  __device__ __forceinline__ uint64_t key(uint32_t shift) const {
+    uint32_t value, pos2;
+    tuple(&value, &pos2);
+    return ((uint64_t)value << shift) | pos2;
   }
 
   // One step for SETS of candidate states: bit o of M = candidate at position j - 1 - o, o in [0, k].
   __device__ __forceinline__ void step_sets(uint32_t code, uint32_t& Mf, uint32_t& Mc) {
-    push(code);
-    const uint32_t vj = lo & mask;
     uint32_t tf, rf, tc, rc;
-    scan(k, &tf, &rf, &tc, &rc);
+    advance(code, &tf, &rf, &tc, &rc);
+    const uint32_t vj = lo & mask;
     const uint32_t low = (1u << k) - 1u;
     uint32_t of = ((Mf >> k) & 1u) ? 1u << (k - tf) : 0u;  // offset in the next frame: j - (j-k+t)
     uint32_t oc = ((Mc >> k) & 1u) ? 1u << (k - tc) : 0u;
