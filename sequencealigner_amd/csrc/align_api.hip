@@ -70,7 +70,6 @@ bool lane_pk16_applicable(const sa_align_batch& b, int K, uint32_t* bias_out) {
     hi = match * std::min(Q, t_pad);
     window = 511;  // the best-cell key keeps 6 bits for the row inside the strip
   } else {
-    if (b.min_qlen != b.max_qlen || b.min_tlen != b.max_tlen) return false;
     lo = (b.type == SA_GLOBAL ? gap * (Q + t_pad) : gap * Q) + std::min(gap, std::min(mismatch, 0L));
     hi = std::max(match, 0L) * std::min(Q, t_pad);
     window = 0x7FFF;

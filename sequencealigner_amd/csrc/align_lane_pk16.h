@@ -18,7 +18,9 @@
 //
 // Preconditions (checked on the host by lane_pk16_applicable): gap <= 0, mismatch <= match,
 // match >= gap, all scores within the 15-bit window; Local additionally gap < 0, mismatch < 0 and a
-// 9-bit score window.  Global/Semiglobal need equal lengths across the batch.
+// 9-bit score window.  Lengths may differ between the pairs of a batch: positions beyond a pair's own
+// query or target hold padding symbols that match nothing, and every pair's result is taken at its own
+// last column / row.
 #ifndef SA_ALIGN_LANE_PK16_H
 #define SA_ALIGN_LANE_PK16_H
 
@@ -138,8 +140,8 @@ template <int MODE, int KS, int KMAX, int SH, bool PERM>
 __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Args& x, uint32_t s,
                                                 uint32_t nstrips, uint32_t maxQ, uint32_t lane,
                                                 const uint32_t* qpk, const uint32_t* tpk, uint32_t* brow,
-                                                uint32_t* dirs, uint2* stage, uint32_t TA, uint32_t TB,
-                                                LanePk16State& st) {
+                                                uint32_t* dirs, uint2* stage, uint32_t QA, uint32_t QB,
+                                                uint32_t TA, uint32_t TB, LanePk16State& st) {
   constexpr int NG = LanePk16Geom<KMAX>::NG;
   constexpr int NGS = LanePk16Geom<KS>::NG;
   const int gap = a.gap;
@@ -261,6 +263,29 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
     if (MODE == SA_LOCAL) {
       const uint32_t ch = nonzero_mask15(best ^ best_before);
       st.br2 = bfi(ch, rep2(r), st.br2);
+    } else if (r == QA || r == QB) {
+      // This is the last column of one (or both) of the lane's pairs: Hc holds S(H[i][Q] + gap).
+      const uint32_t hm = (r == QA ? 0x0000FFFFu : 0u) | (r == QB ? 0xFFFF0000u : 0u);
+      if (MODE == SA_SEMIGLOBAL) {
+        // first strict maximum > 0 over the rows in increasing order (src/alignment.cpp:87-92)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const uint32_t i = i0 + 1 + k;
+          const uint32_t nb = pk_max_u16(st.sgbest, Hc[k]);
+          uint32_t ch = nonzero_mask15(nb ^ st.sgbest) & hm;
+          if (i > TA) ch &= 0xFFFF0000u;  // rows beyond the pair's target are padding
+          if (i > TB) ch &= 0x0000FFFFu;
+          st.sgbest = bfi(ch, nb, st.sgbest);
+          st.sgrow2 = bfi(ch, rep2(i), st.sgrow2);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const uint32_t i = i0 + 1 + k;
+          if (i == TA && r == QA) st.final2 = (st.final2 & 0xFFFF0000u) | (Hc[k] & 0x0000FFFFu);
+          if (i == TB && r == QB) st.final2 = (st.final2 & 0x0000FFFFu) | (Hc[k] & 0xFFFF0000u);
+        }
+      }
     }
   }
   if (MODE == SA_LOCAL) {
@@ -268,26 +293,6 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
     const uint32_t rows = rep2(i0 + 64) - (best & 0x003F003Fu);  // i0 + 1 + k, k = 63 - low bits
     st.bi2 = bfi(ch, rows, st.bi2);
     st.best = best | 0x003F003Fu;  // a later strip (larger rows) wins only with a strictly larger score
-  } else if (MODE == SA_SEMIGLOBAL) {
-    // column Q (= maxQ for the equal-length batches this kernel accepts): first strict maximum > 0 over
-    // rows in increasing order (src/alignment.cpp:87-92); Hc holds S(H[i][Q] + gap).
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const uint32_t i = i0 + 1 + k;
-      const uint32_t nb = pk_max_u16(st.sgbest, Hc[k]);
-      uint32_t ch = nonzero_mask15(nb ^ st.sgbest);
-      if (i > TA) ch &= 0xFFFF0000u;  // rows beyond the pair's target are padding
-      if (i > TB) ch &= 0x0000FFFFu;
-      st.sgbest = bfi(ch, nb, st.sgbest);
-      st.sgrow2 = bfi(ch, rep2(i), st.sgrow2);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const uint32_t i = i0 + 1 + k;
-      if (i == TA) st.final2 = (st.final2 & 0xFFFF0000u) | (Hc[k] & 0x0000FFFFu);
-      if (i == TB) st.final2 = (st.final2 & 0x0000FFFFu) | (Hc[k] & 0xFFFF0000u);
-    }
   }
 }
 
@@ -297,23 +302,24 @@ __device__ __forceinline__ void lane_pk16_strips(const AlignArgs& a, const Pk16A
                                                  uint32_t rem, uint32_t nstrips, uint32_t maxQ,
                                                  uint32_t lane, const uint32_t* qpk, const uint32_t* tpk,
                                                  uint32_t* brow, uint32_t* dirs, uint2* stage,
-                                                 uint32_t TA, uint32_t TB, LanePk16State& st) {
+                                                 uint32_t QA, uint32_t QB, uint32_t TA, uint32_t TB,
+                                                 LanePk16State& st) {
   for (uint32_t s = 0; s < nfull; ++s)
-    lane_pk16_strip<MODE, K, K, SH, PERM>(a, x, s, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, TA,
-                                          TB, st);
+    lane_pk16_strip<MODE, K, K, SH, PERM>(a, x, s, nstrips, maxQ, lane, qpk, tpk, brow, dirs, stage, QA,
+                                          QB, TA, TB, st);
   if (rem) {
     if (rem <= 16)
       lane_pk16_strip<MODE, 16, K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
-                                             stage, TA, TB, st);
+                                             stage, QA, QB, TA, TB, st);
     else if (rem <= 32 || K <= 32)
       lane_pk16_strip<MODE, (K < 32 ? K : 32), K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk,
-                                                            brow, dirs, stage, TA, TB, st);
+                                                            brow, dirs, stage, QA, QB, TA, TB, st);
     else if (rem <= 48 || K <= 48)
       lane_pk16_strip<MODE, (K < 48 ? K : 48), K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk,
-                                                            brow, dirs, stage, TA, TB, st);
+                                                            brow, dirs, stage, QA, QB, TA, TB, st);
     else
       lane_pk16_strip<MODE, K, K, SH, PERM>(a, x, nfull, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
-                                            stage, TA, TB, st);
+                                            stage, QA, QB, TA, TB, st);
   }
 }
 
@@ -368,11 +374,11 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   if (tables) {
     const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
     lane_pk16_strips<MODE, K, SH, true>(a, x, nfull, rem, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
-                                        stage, TA, TB, st);
+                                        stage, QA, QB, TA, TB, st);
   } else {
     const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
     lane_pk16_strips<MODE, K, SH, false>(a, x, nfull, rem, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
-                                         stage, TA, TB, st);
+                                         stage, QA, QB, TA, TB, st);
   }
 
   // unpack the two pairs' results
