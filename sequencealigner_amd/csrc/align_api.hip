@@ -3,6 +3,7 @@
 #include "align_lane_i32.h"
 #include "align_lane_pk16.h"
 #include "align_wave_i32.h"
+#include "align_wave_pk16.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -49,6 +50,7 @@ struct Plan {
   uint32_t entry_match, entry_mismatch;
   int wave_c;                 // wavefront kernels: query columns per lane (8 or 16)
   bool coop;                  // wavefront kernels: one wave per (pair, strip), all resident
+  bool wave_pk;               // wavefront kernels: packed 16-bit scores, two pairs per wave
   size_t bytes_per_block;     // workspace bytes per workgroup (4 units)
   uint32_t pairs_per_block;
   const char* name;
@@ -77,6 +79,24 @@ bool lane_pk16_applicable(const sa_align_batch& b, int K, uint32_t* bias_out) {
   const long bias = 1 - lo;  // S(x) = x + bias >= 1 for every value formed
   if (hi + bias + (match - gap) + 1 > window) return false;
   if (Q >= 0x7FFF || t_pad + 64 >= 0x7FFF) return false;  // packed row/column indices
+  *bias_out = (uint32_t)bias;
+  return true;
+}
+
+// Can the packed 16-bit wavefront kernel reproduce this batch exactly?  (Preconditions at the top of
+// align_wave_pk16.h; the matrix it sweeps is padded to whole strips of columns.)
+bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
+  if (b.type == SA_LOCAL) return false;
+  const long match = b.match, mismatch = b.mismatch, gap = b.gap;
+  if (gap > 0 || mismatch > match || match < gap) return false;
+  const long Q = b.max_qlen, T = b.max_tlen;
+  if (Q == 0 || T == 0) return false;
+  const long strip = 64 * kWavePkCols;
+  const long q_pad = (Q + strip - 1) / strip * strip;
+  const long lo = (b.type == SA_GLOBAL ? gap * (q_pad + T) : gap * q_pad) + std::min(gap, std::min(mismatch, 0L));
+  const long hi = std::max(match, 0L) * std::min(Q, T);
+  const long bias = 1 - lo;
+  if (hi + bias + (match - gap) + 1 > 0x7FFF) return false;
   *bias_out = (uint32_t)bias;
   return true;
 }
@@ -130,13 +150,17 @@ Plan make_plan(const sa_align_batch& b) {
     const char* force_coop = getenv("SA_FORCE_COOP");
     pl.coop = b.n * strips8 <= 2048 && (force_coop ? atoi(force_coop) != 0 : (b.n <= 256 && max_q > 1024));
     pl.wave_c = pl.coop ? coop_c : 16;
+    uint32_t wbias = 0;
+    pl.wave_pk = !pl.coop && !force_i32 && wave_pk16_applicable(b, &wbias);
     const uint32_t strip = 64 * pl.wave_c;
     pl.family = Family::WaveI32;
-    pl.name = pl.coop ? "wave_i32_coop" : "wave_i32";
+    pl.name = pl.coop ? "wave_i32_coop" : pl.wave_pk ? "wave_pk16" : "wave_i32";
     pl.K = pl.wave_c;
+    pl.bias = wbias;
     pl.nstrips = (max_q + strip - 1) / strip;
-    pl.pairs_per_unit = 1;
-    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 * (pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
+    pl.pairs_per_unit = pl.wave_pk ? 2 : 1;
+    pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 *
+                          (pl.wave_pk ? 8 : pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
     pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * 2 * (pl.coop ? 2 : 1);  // 64-bit entries
   } else if (pk16_ok) {
     pl.family = Family::LanePk16;
@@ -280,7 +304,7 @@ int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, 
   if (need_traceback) {
     {
       Timed tm(stream, 2);
-      hipLaunchKernelGGL((traceback_wave<MODE, C>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
+      hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtI32<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
     }
     SA_HIP_TRY(hipGetLastError());
   }
@@ -288,9 +312,32 @@ int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, 
 }
 
 template <int MODE>
+int launch_wave_pk16(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
+  if constexpr (MODE == SA_LOCAL) {
+    return fail(SA_ERR_ARGUMENT, "packed wavefront kernel chosen for Local");
+  } else {
+    {
+      Timed tm(stream, 1);
+      hipLaunchKernelGGL((fill_wave_pk16<MODE>), dim3((a.pairs_in_pass + 1) / 2), dim3(64), 0, stream, a,
+                         pl.bias);
+    }
+    SA_HIP_TRY(hipGetLastError());
+    if (need_traceback) {
+      {
+        Timed tm(stream, 2);
+        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
+      }
+      SA_HIP_TRY(hipGetLastError());
+    }
+    return SA_OK;
+  }
+}
+
+template <int MODE>
 int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t* qpk, uint32_t* tpk,
                 const AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
+  if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE>(pl, a, stream, need_tb);
   if (pl.family == Family::WaveI32)
     return !pl.coop          ? launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb)
            : pl.wave_c == 4 ? launch_wave_i32<MODE, 4, true>(a, co, stream, need_tb)

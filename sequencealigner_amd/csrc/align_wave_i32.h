@@ -337,26 +337,42 @@ __global__ void wave_local_reduce(AlignArgs a, WaveCoop co) {
   a.end_r[pl] = best ? br : 0;
 }
 
-// Traceback + run-length encoding for the wavefront layout, one wavefront per pair (same rules as
-// traceback_kernel).  The direction words of 64 consecutive steps of a strip are one contiguous block:
-// the wave copies that block, the strip's query symbols and the target symbols of the rows it spans into
-// LDS and walks inside it; every lane follows the same path, lane 0 writes the runs.
-template <int MODE, int C>
+// How a wavefront kernel stores its direction words, as seen by the traceback.
+template <int C_>
+struct WaveFmtI32 {
+  static constexpr int C = C_;
+  using word_t = typename WaveWord<C_>::type;
+  static constexpr uint32_t kTileSteps = 64;  // steps of one LDS tile
+  static constexpr uint32_t kPairs = 1;       // pairs that share a wavefront's words
+  __device__ static __forceinline__ uint32_t decode(word_t w, uint32_t k, uint32_t) {
+    return WaveI32Layout<C_>::decode(w, k);
+  }
+};
+
+// Traceback + run-length encoding for the wavefront layouts, one wavefront per pair (same rules as
+// traceback_kernel).  The direction words of kTileSteps consecutive steps of a strip are one contiguous
+// block: the wave copies that block, the strip's query symbols and the target symbols of the rows it
+// spans into LDS and walks inside it; every lane follows the same path, lane 0 writes the runs.
+template <int MODE, class Fmt>
 __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
-  using word_t = typename WaveWord<C>::type;
+  using word_t = typename Fmt::word_t;
+  constexpr int C = Fmt::C;
   constexpr uint32_t STRIP = 64 * C;
-  __shared__ __attribute__((aligned(16))) word_t tile[64 * 64];
+  constexpr uint32_t TS = Fmt::kTileSteps;
+  __shared__ __attribute__((aligned(16))) word_t tile[TS * 64];
   __shared__ uint8_t qs[STRIP];
   __shared__ uint8_t ts[128];
   const uint32_t lane = threadIdx.x;
   const uint32_t pl = blockIdx.x;
   if (pl >= a.pairs_in_pass) return;
   const uint32_t p = a.pair_base + pl;
+  const uint32_t half = pl % Fmt::kPairs;
   const uint8_t* q = a.q + a.q_off[p];
   const uint8_t* t = a.t + a.t_off[p];
   const uint32_t Q = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
   const uint32_t T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
-  const word_t* dirs = reinterpret_cast<const word_t*>(a.dirs + (uint64_t)pl * a.dirs_unit_stride);
+  const word_t* dirs =
+      reinterpret_cast<const word_t*>(a.dirs + (uint64_t)(pl / Fmt::kPairs) * a.dirs_unit_stride);
   const uint32_t nsteps = a.max_t + 64;
   uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
   uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
@@ -364,8 +380,8 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
-  uint32_t tile_s = ~0u, tile_lo = 0;  // the tile holds steps [tile_lo, tile_lo + 63] of strip tile_s
-  constexpr uint32_t kVecPerLane = 64 * sizeof(word_t) / 16;
+  uint32_t tile_s = ~0u, tile_lo = 0;  // the tile holds steps [tile_lo, tile_lo + TS) of strip tile_s
+  constexpr uint32_t kVecPerLane = TS * sizeof(word_t) / 16;
   uint4 pre[kVecPerLane];              // the block below, on its way in
   uint32_t pre_s = ~0u, pre_lo = 0;
   uint32_t ts_base = 0;                // ts[x] = t[ts_base + x]
@@ -380,9 +396,9 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       const uint32_t c = r - 1;
       const uint32_t s = c / STRIP, L = (c % STRIP) / C;
       const uint32_t st = i + L;
-      if (s != tile_s || (st & ~63u) != tile_lo) {
+      if (s != tile_s || (st & ~(TS - 1)) != tile_lo) {
         __syncthreads();
-        const uint32_t lo = st & ~63u;
+        const uint32_t lo = st & ~(TS - 1);
         uint4* dst = reinterpret_cast<uint4*>(tile);
         if (s == pre_s && lo == pre_lo) {
 #pragma unroll
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
           tile_s = s;
         }
         tile_lo = lo;
-        // rows of the tile: i = st' - L' for st' in [lo, lo+63], L' in [0, 63]
+        // rows of the tile: i = st' - L' for st' in [lo, lo+TS), L' in [0, 63]
         ts_base = lo >= 64 ? lo - 64 : 0;  // index of row (lo - 63) is lo - 64
 #pragma unroll
         for (uint32_t x = 0; x < 2; ++x) {
@@ -409,9 +425,9 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
           ts[x * 64 + lane] = idx < T ? t[idx] : 0;
         }
         // the path leaves a tile downwards: fetch the block below while walking this one
-        if (lo >= 64) {
+        if (lo >= TS) {
           pre_s = s;
-          pre_lo = lo - 64;
+          pre_lo = lo - TS;
           const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + pre_lo) * 64);
 #pragma unroll
           for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = src[x * 64 + lane];
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       const uint32_t cx = ok ? rx - 1 : c;
       const uint32_t Lx = (cx % STRIP) / C, kx = cx % C, stx = (ok ? ix : i) + Lx;
       ok = ok && stx >= tile_lo;
-      const uint32_t dx = ok ? WaveI32Layout<C>::decode(tile[(stx - tile_lo) * 64 + Lx], kx) : (uint32_t)DIR_NONE;
+      const uint32_t dx = ok ? Fmt::decode(tile[(stx - tile_lo) * 64 + Lx], kx, half) : (uint32_t)DIR_NONE;
       const bool eqx = ok && ts[ix - 1 - ts_base] == qs[cx % STRIP];
       const uint64_t eqm = __ballot(eqx);
       bool diag_ok = ok && dx == DIR_DIAG;

@@ -1,0 +1,232 @@
+// Wavefront DP fill (see align_wave_i32.h for the sweep) with packed 16-bit scores: TWO pairs per
+// wavefront, pair A in the low halves and pair B in the high halves of every register, Global and
+// Semiglobal only.  Number format as in align_lane_pk16.h: S(x) = x + BIAS with bit 15 of each half set,
+// so plain 32-bit add/sub act as two independent 16-bit operations and unsigned packed max orders the
+// halves.  Per cell (both pairs): xor + packed min (symbols differ?), add, packed multiply-add (diagonal
+// candidate), two packed max, two packed subtractions whose sign bits are the direction flags (one
+// v_perm spreads the four signs into four bytes, one v_and_or drops them into the step's word), one
+// subtract for H + gap: 11 instructions for two cells.
+//
+// The two pairs may have different lengths: the sweep covers the longer query and target, positions
+// beyond a pair's own sequence hold padding symbols that match nothing, and every pair's result is
+// taken at its own last column / row.  One wavefront walks the strips of its two pairs one after the
+// other (the sequential mode of the 32-bit kernel; thousands of pairs per launch).
+//
+// Preconditions (checked on the host): gap <= 0, mismatch <= match, gap <= match, every value of the
+// padded matrix within the 15-bit window.
+#ifndef SA_ALIGN_WAVE_PK16_H
+#define SA_ALIGN_WAVE_PK16_H
+
+#include "align_lane_pk16.h"
+#include "align_wave_i32.h"
+
+namespace sa {
+
+constexpr int kWavePkCols = 16;  // query columns per lane
+
+// Direction storage: per (strip, step, lane) one uint2 - .x cells 0-7, .y cells 8-15 of the lane's
+// columns; byte h = "left candidate != m" of pair h, byte 2+h = "diag candidate != m", bit = cell % 8.
+//   word[(s * nsteps + st) * 64 + L],  st = i + L,  nsteps = max_t + 64.
+struct WaveFmtPk16 {
+  static constexpr int C = kWavePkCols;
+  using word_t = uint2;
+  static constexpr uint32_t kTileSteps = 32;
+  static constexpr uint32_t kPairs = 2;
+  __device__ static __forceinline__ uint32_t decode(uint2 w, uint32_t k, uint32_t half) {
+    const uint32_t word = k < 8 ? w.x : w.y, b = k & 7;
+    const uint32_t not_diag = (word >> (16 + 8 * half + b)) & 1u;
+    const uint32_t not_left = (word >> (8 * half + b)) & 1u;
+    return !not_diag ? DIR_DIAG : (!not_left ? DIR_LEFT : DIR_UP);
+  }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias) {
+  static_assert(MODE != SA_LOCAL, "packed wavefront kernel: Global and Semiglobal only");
+  constexpr int C = kWavePkCols;
+  constexpr uint32_t STRIP = 64 * C;
+  __shared__ uint32_t tring[256];  // target symbols of both pairs, index = position & 255
+  const uint32_t lane = threadIdx.x;
+  const uint32_t unit = blockIdx.x;
+  const uint32_t plA = 2 * unit, plB = plA + 1;
+  if (plA >= a.pairs_in_pass) return;
+  const bool hasB = plB < a.pairs_in_pass;
+  const uint32_t pA = a.pair_base + plA, pB = a.pair_base + (hasB ? plB : plA);
+  const uint8_t* qA = a.q + a.q_off[pA];
+  const uint8_t* tA = a.t + a.t_off[pA];
+  const uint8_t* qB = a.q + a.q_off[pB];
+  const uint8_t* tB = a.t + a.t_off[pB];
+  const uint32_t QA = __builtin_amdgcn_readfirstlane((uint32_t)(a.q_off[pA + 1] - a.q_off[pA]));
+  const uint32_t TA = __builtin_amdgcn_readfirstlane((uint32_t)(a.t_off[pA + 1] - a.t_off[pA]));
+  const uint32_t QB = hasB ? __builtin_amdgcn_readfirstlane((uint32_t)(a.q_off[pB + 1] - a.q_off[pB])) : 0;
+  const uint32_t TB = hasB ? __builtin_amdgcn_readfirstlane((uint32_t)(a.t_off[pB + 1] - a.t_off[pB])) : 0;
+  const int gap = a.gap;
+  const uint32_t Q = QA > QB ? QA : QB, T = TA > TB ? TA : TB;  // the sweep covers both pairs
+
+  // per pair: best last-column score (Semiglobal) / final score (Global), kept by the lane that owns
+  // the pair's last column
+  int bestA = 0, bestB = 0, finalA = 0, finalB = 0;
+  uint32_t biA = 0, biB = 0;
+
+  if (Q != 0 && T != 0) {
+    const uint32_t G = kGuard2;
+    auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v)) | G; };
+    const uint32_t gsub2 = rep2((uint32_t)(-gap));                               // |gap|
+    const uint32_t mg2 = rep2((uint32_t)(a.match - gap));                        // match - gap >= 0
+    const uint32_t negdelta2 = rep2((uint32_t)(a.mismatch - a.match) & 0xFFFFu);  // mod 2^16
+    const uint32_t one2 = 0x00010001u;
+    const uint32_t nstrips_p = (Q + STRIP - 1) / STRIP;
+    uint2* dirs = reinterpret_cast<uint2*>(a.dirs + (uint64_t)unit * a.dirs_unit_stride);
+    uint64_t* bcol = reinterpret_cast<uint64_t*>(a.brow + (uint64_t)unit * a.brow_unit_stride);
+    const uint32_t nsteps = a.max_t + 64;
+    // where each pair's last column lives (a pair without cells never matches a strip)
+    const uint32_t lastA = QA ? QA - 1 : 0, lastB = QB ? QB - 1 : 0;
+    const uint32_t stripA = (QA && TA) ? lastA / STRIP : ~0u, stripB = (QB && TB) ? lastB / STRIP : ~0u;
+    const uint32_t laneA = (lastA % STRIP) / C, regA = lastA % C;
+    const uint32_t laneB = (lastB % STRIP) / C, regB = lastB % C;
+
+    for (uint32_t s = 0; s < nstrips_p; ++s) {
+      const uint32_t c0 = s * STRIP + lane * C;  // this lane's columns are r = c0+1 .. c0+C
+      const bool last_strip = (s + 1 == nstrips_p);
+      uint32_t qc[C], Hg[C];  // query symbols (A | B << 16); S(H[i-1][column] + gap)
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const uint32_t sa = (c0 + k < QA) ? (uint32_t)qA[c0 + k] : kQueryPad;
+        const uint32_t sb = (c0 + k < QB) ? (uint32_t)qB[c0 + k] : kQueryPad;
+        qc[k] = sa | (sb << 16);
+        Hg[k] = SG(border_row0<MODE>((int)(c0 + 1 + k), gap) + gap);
+      }
+      uint32_t ldiag = SG(border_row0<MODE>((int)c0, gap) + gap);  // S(H[i-1][c0] + gap), lane's first row
+      uint32_t lastcol = 0, bnext = 0, bout = 0;
+      auto tsym = [&](uint32_t pos) -> uint32_t {  // both pairs' target symbols at a position
+        const uint32_t sa = pos < TA ? (uint32_t)tA[pos] : kTargetPad;
+        const uint32_t sb = pos < TB ? (uint32_t)tB[pos] : kTargetPad;
+        return sa | (sb << 16);
+      };
+      if (lane == 0) tring[0] = tsym(0);
+      uint32_t tc_next = tsym(0);  // lane 0's first row; the other lanes read theirs from the ring
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing stays pending into the step loop
+      const uint32_t steps = T + 63;
+      uint2* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
+      auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const uint32_t j = (st - 1) & 63;
+        const uint32_t tc = tc_next;
+        tc_next = tring[(st - lane) & 255u];  // position of row st + 1 - lane
+        const uint32_t from_left = (uint32_t)dpp_from_lane_below((int)lastcol);
+        const uint32_t first = (s == 0) ? SG(border_col0<MODE>((int)st, gap) + gap)
+                                        : (uint32_t)__builtin_amdgcn_readlane((int)bnext, j);
+        const uint32_t recv = lane == 0 ? first : from_left;
+        const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
+        if (FULL || (st > lane && i <= T)) {
+          uint32_t diag = ldiag, left = recv, acc0 = 0, acc1 = 0;
+#pragma unroll
+          for (int k = 0; k < C; ++k) {
+            const uint32_t up = Hg[k];
+            const uint32_t ne = pk_min_u16(tc ^ qc[k], one2);  // 1 where the symbols differ
+            const uint32_t d = pk_mad_u16(ne, negdelta2, diag + mg2);
+            const uint32_t m = pk_max_u16(pk_max_u16(d, up), left);
+            const uint32_t signs = __builtin_amdgcn_perm(pk_sub_u16(d, m), pk_sub_u16(left, m), 0x0B0A0908u);
+            if (k < 8)
+              acc0 = and_or(signs, 0x01010101u << (k & 7), acc0);
+            else
+              acc1 = and_or(signs, 0x01010101u << (k & 7), acc1);
+            diag = up;
+            left = m - gsub2;  // S(H[i][column] + gap)
+            Hg[k] = left;
+          }
+          drow[(uint64_t)st * 64] = make_uint2(acc0, acc1);
+          ldiag = recv;
+          lastcol = left;
+          if (s == stripA || s == stripB) {  // a pair's last column is in this strip
+            uint32_t pickA = 0, pickB = 0;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+              pickA |= Hg[k] & ((uint32_t)k == regA ? 0x0000FFFFu : 0u);
+              pickB |= Hg[k] & ((uint32_t)k == regB ? 0xFFFF0000u : 0u);
+            }
+            if (s == stripA && lane == laneA && i <= TA) {
+              const int v = (int)(pickA & 0x7FFFu) - (int)bias - gap;
+              if (MODE == SA_SEMIGLOBAL && v > bestA) {  // src/alignment.cpp:87-92, rows in increasing order
+                bestA = v;
+                biA = i;
+              }
+              if (MODE == SA_GLOBAL && i == TA) finalA = v;
+            }
+            if (s == stripB && lane == laneB && i <= TB) {
+              const int v = (int)((pickB >> 16) & 0x7FFFu) - (int)bias - gap;
+              if (MODE == SA_SEMIGLOBAL && v > bestB) {
+                bestB = v;
+                biB = i;
+              }
+              if (MODE == SA_GLOBAL && i == TB) finalB = v;
+            }
+          }
+        }
+        // lane 63 finished row st - 63 of the strip's last column: collect 64 of them, store coalesced
+        if (!last_strip && (FULL || st >= 64)) {
+          const uint32_t v63 = (uint32_t)__builtin_amdgcn_readlane((int)lastcol, 63);
+          const uint32_t row = st - 63;  // 1 ..
+          const uint32_t slot = (row - 1) & 63;
+          bout = lane == slot ? v63 : bout;
+          if (slot == 63 || row == T) {
+            const uint32_t base = row - slot;  // first row held in bout
+            if (base + lane <= row)
+              __hip_atomic_store(&bcol[base + lane], (uint64_t)bout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      };
+      for (uint32_t b0 = 1; b0 <= steps; b0 += 64) {  // batches of 64 steps
+        {
+          const uint32_t pos = b0 + lane;  // target positions b0 .. b0+63
+          tring[pos & 255u] = tsym(pos);
+        }
+        if (s > 0) {  // rows b0 .. b0+63 of the previous strip's last column (written by this wave)
+          const uint32_t row = b0 + lane;
+          bnext = row <= T ? (uint32_t)__hip_atomic_load(&bcol[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : 0u;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, so that no step has to wait on it
+        if (b0 >= 64 && b0 + 63 <= T) {
+          for (uint32_t x = 0; x < 64; ++x) step(b0 + x, std::true_type{});
+        } else {
+          const uint32_t e = b0 + 63 < steps ? b0 + 63 : steps;
+          for (uint32_t st = b0; st <= e; ++st) step(st, std::false_type{});
+        }
+      }
+    }
+    bestA = __builtin_amdgcn_readlane(bestA, laneA);
+    biA = (uint32_t)__builtin_amdgcn_readlane((int)biA, laneA);
+    finalA = __builtin_amdgcn_readlane(finalA, laneA);
+    bestB = __builtin_amdgcn_readlane(bestB, laneB);
+    biB = (uint32_t)__builtin_amdgcn_readlane((int)biB, laneB);
+    finalB = __builtin_amdgcn_readlane(finalB, laneB);
+  }
+  if (lane != 0) return;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && !hasB) break;
+    const uint32_t pl = h ? plB : plA, p = h ? pB : pA;
+    const uint32_t Qh = h ? QB : QA, Th = h ? TB : TA;
+    const int best = h ? bestB : bestA, fin = h ? finalB : finalA;
+    uint32_t bi = h ? biB : biA;
+    int score;
+    if (Qh == 0 || Th == 0) {  // no cells: the result is a border value
+      score = (MODE == SA_GLOBAL) ? (Th == 0 ? border_row0<MODE>((int)Qh, gap) : border_col0<MODE>((int)Th, gap))
+                                  : border_row0<MODE>((int)Qh, gap);
+      bi = (MODE == SA_GLOBAL) ? Th : 0;
+    } else if (MODE == SA_GLOBAL) {
+      score = fin;
+      bi = Th;
+    } else {
+      score = bi ? best : border_row0<MODE>((int)Qh, gap);
+    }
+    a.score[p] = score;
+    a.end_i[pl] = bi;
+    a.end_r[pl] = Qh;
+  }
+}
+
+}  // namespace sa
+
+#endif

@@ -40,6 +40,10 @@ def _force_family(name):
     import os
     os.environ.pop("SA_FORCE_FAMILY", None)
     os.environ.pop("SA_FORCE_COOP", None)
+    os.environ.pop("SA_FORCE_I32", None)
+    if name == "wave32":    # one wave per pair, 32-bit scores only
+        os.environ["SA_FORCE_I32"] = "1"
+        name = "wave"
     if name == "coop":      # wavefront kernels, one wave per (pair, strip) wherever the batch allows it
         os.environ["SA_FORCE_FAMILY"] = "wave"
         os.environ["SA_FORCE_COOP"] = "1"
@@ -50,7 +54,7 @@ def _force_family(name):
         os.environ["SA_FORCE_FAMILY"] = name
 
 
-@pytest.fixture(params=["auto", "lane", "wave", "coop"])
+@pytest.fixture(params=["auto", "lane", "wave", "wave32", "coop"])
 def family(request):
     _force_family(None if request.param == "auto" else request.param)
     yield request.param
@@ -174,7 +178,7 @@ def test_full_size_properties():
     assert ((tb + t_used) <= 300).all()
 
 
-@pytest.fixture(params=["wave", "coop"])
+@pytest.fixture(params=["wave", "wave32", "coop"])
 def wave_mode(request):
     _force_family(request.param)
     yield request.param
@@ -191,7 +195,9 @@ def test_long_pairs_vs_oracle(oracle, wave_mode):
         cases = _oracle_cases(oracle, pairs, typ, m, x, g)
         assert len(cases) == 6
         b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
-        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" else "wave_i32")
+        packed = wave_mode == "wave" and typ != 1   # Global / Semiglobal within the 16-bit window
+        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" else
+                                   "wave_pk16" if packed else "wave_i32")
         _run_group(cases)
     # one pair with unequal lengths, crossing a strip boundary exactly (2048 columns) and not (2049)
     for ql in (2048, 2049, 1025):
