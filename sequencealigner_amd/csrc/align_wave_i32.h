@@ -359,7 +359,12 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   constexpr int C = Fmt::C;
   constexpr uint32_t STRIP = 64 * C;
   constexpr uint32_t TS = Fmt::kTileSteps;
-  __shared__ __attribute__((aligned(16))) word_t tile[TS * 64];
+  constexpr uint32_t TW = 16;                           // lanes (column blocks) of one LDS tile
+  constexpr uint32_t WPV = 16 / sizeof(word_t);         // words per 16-byte vector
+  constexpr uint32_t VPR = TW / WPV;                    // vectors per tile row
+  constexpr uint32_t kVecPerLane = TS * VPR / 64;       // vectors a lane moves per tile
+  static_assert(TW % WPV == 0 && (TS * VPR) % 64 == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) word_t tile[TS * TW];
   __shared__ uint8_t qs[STRIP];
   __shared__ uint8_t ts[128];
   const uint32_t lane = threadIdx.x;
@@ -380,11 +385,21 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
-  uint32_t tile_s = ~0u, tile_lo = 0;  // the tile holds steps [tile_lo, tile_lo + TS) of strip tile_s
-  constexpr uint32_t kVecPerLane = TS * sizeof(word_t) / 16;
-  uint4 pre[kVecPerLane];              // the block below, on its way in
-  uint32_t pre_s = ~0u, pre_lo = 0;
+  // The tile holds steps [tile_lo, tile_lo + TS) x lanes [tile_lb, tile_lb + TW) of strip tile_s: the
+  // path moves towards smaller steps and lanes, about one lane per C diagonal moves.
+  uint32_t tile_s = ~0u, tile_lo = 0, tile_lb = 0;
+  uint4 pre[kVecPerLane];              // the predicted next tile, on its way in
+  uint32_t pre_s = ~0u, pre_lo = 0, pre_lb = 0;
   uint32_t ts_base = 0;                // ts[x] = t[ts_base + x]
+  // lane base of a tile whose top lanes include L (vector-aligned, inside the 64 lanes)
+  auto lane_base = [&](uint32_t top) -> uint32_t {
+    const uint32_t lb = top + WPV >= TW ? ((top + WPV - TW) / WPV) * WPV : 0u;
+    return lb > 64 - TW ? 64 - TW : lb;
+  };
+  auto tile_vec = [&](uint32_t s, uint32_t lo, uint32_t lb, uint32_t x) -> const uint4* {
+    const uint32_t v = x * 64 + lane, row = v / VPR, colv = v % VPR;
+    return reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + lo + row) * 64 + lb) + colv;
+  };
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
@@ -396,17 +411,18 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       const uint32_t c = r - 1;
       const uint32_t s = c / STRIP, L = (c % STRIP) / C;
       const uint32_t st = i + L;
-      if (s != tile_s || (st & ~(TS - 1)) != tile_lo) {
+      if (s != tile_s || (st & ~(TS - 1)) != tile_lo || L < tile_lb || L >= tile_lb + TW) {
         __syncthreads();
         const uint32_t lo = st & ~(TS - 1);
         uint4* dst = reinterpret_cast<uint4*>(tile);
-        if (s == pre_s && lo == pre_lo) {
+        if (s == pre_s && lo == pre_lo && L >= pre_lb && L < pre_lb + TW) {
+          tile_lb = pre_lb;
 #pragma unroll
           for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = pre[x];
         } else {
-          const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + lo) * 64);
+          tile_lb = lane_base(L);
 #pragma unroll
-          for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = src[x * 64 + lane];
+          for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = *tile_vec(s, lo, tile_lb, x);
         }
         if (s != tile_s) {
 #pragma unroll
@@ -424,13 +440,15 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
           const uint32_t idx = ts_base + x * 64 + lane;
           ts[x * 64 + lane] = idx < T ? t[idx] : 0;
         }
-        // the path leaves a tile downwards: fetch the block below while walking this one
+        // the path leaves a tile downwards, TS / C lanes further left on a diagonal: fetch that tile
+        // while walking this one
         if (lo >= TS) {
           pre_s = s;
           pre_lo = lo - TS;
-          const uint4* src = reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + pre_lo) * 64);
+          const uint32_t drift = TS / C > 3 ? TS / C - 3 : 0;
+          pre_lb = lane_base(L > drift ? L - drift : 0);
 #pragma unroll
-          for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = src[x * 64 + lane];
+          for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = *tile_vec(s, pre_lo, pre_lb, x);
         } else {
           pre_s = ~0u;
         }
@@ -442,8 +460,9 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       bool ok = lane < i && lane < r && rx - 1 >= s * STRIP;
       const uint32_t cx = ok ? rx - 1 : c;
       const uint32_t Lx = (cx % STRIP) / C, kx = cx % C, stx = (ok ? ix : i) + Lx;
-      ok = ok && stx >= tile_lo;
-      const uint32_t dx = ok ? Fmt::decode(tile[(stx - tile_lo) * 64 + Lx], kx, half) : (uint32_t)DIR_NONE;
+      ok = ok && stx >= tile_lo && Lx >= tile_lb;
+      const uint32_t dx =
+          ok ? Fmt::decode(tile[(stx - tile_lo) * TW + (Lx - tile_lb)], kx, half) : (uint32_t)DIR_NONE;
       const bool eqx = ok && ts[ix - 1 - ts_base] == qs[cx % STRIP];
       const uint64_t eqm = __ballot(eqx);
       bool diag_ok = ok && dx == DIR_DIAG;

@@ -30,7 +30,7 @@ constexpr int kWavePkCols = 16;  // query columns per lane
 struct WaveFmtPk16 {
   static constexpr int C = kWavePkCols;
   using word_t = uint2;
-  static constexpr uint32_t kTileSteps = 32;
+  static constexpr uint32_t kTileSteps = 64;
   static constexpr uint32_t kPairs = 2;
   __device__ static __forceinline__ uint32_t decode(uint2 w, uint32_t k, uint32_t half) {
     const uint32_t word = k < 8 ? w.x : w.y, b = k & 7;
