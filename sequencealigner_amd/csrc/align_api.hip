@@ -132,7 +132,9 @@ Plan make_plan(const sa_align_batch& b) {
     const double waves_lane = std::ceil(b.n / (pk16_ok ? 128.0 : 64.0));
     const double lane_rate = std::min(waves_lane / 1024.0, 1.0) * (pk16_ok ? 5.3 : 0.9);
     const double strip_eff = max_q / (std::ceil(max_q / 1024.0) * 1024.0) * max_t / (max_t + 63.0);
-    const double wave_rate = std::min(b.n / 2048.0, 1.0) * 3.0 * strip_eff;
+    uint32_t unused_bias = 0;
+    const bool wpk = !force_i32 && wave_pk16_applicable(b, &unused_bias);
+    const double wave_rate = std::min(b.n / (wpk ? 6144.0 : 2048.0), 1.0) * (wpk ? 4.1 : 3.0) * strip_eff;
     want_wave = wave_rate > lane_rate;
   }
   if (b.type == SA_LOCAL &&

@@ -5,7 +5,8 @@
 // halves.  Per cell (both pairs): xor + packed min (symbols differ?), add, packed multiply-add (diagonal
 // candidate), two packed max, two packed subtractions whose sign bits are the direction flags (one
 // v_perm spreads the four signs into four bytes, one v_and_or drops them into the step's word), one
-// subtract for H + gap: 11 instructions for two cells.
+// subtract for H + gap: 11 instructions for two cells.  A row's cells are computed in two passes, the
+// independent part first, so that only max + subtract remain on the dependent chain.
 //
 // The two pairs may have different lengths: the sweep covers the longer query and target, positions
 // beyond a pair's own sequence hold padding symbols that match nothing, and every pair's result is
@@ -119,22 +120,40 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
         const uint32_t recv = lane == 0 ? first : from_left;
         const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
         if (FULL || (st > lane && i <= T)) {
-          uint32_t diag = ldiag, left = recv, acc0 = 0, acc1 = 0;
+          // pass 1 (no dependencies between cells): diagonal candidates from the previous row's values
+          // still held in Hg, already maximised with the "up" candidate
+          uint32_t dc[C], mx[C];
 #pragma unroll
           for (int k = 0; k < C; ++k) {
-            const uint32_t up = Hg[k];
+            const uint32_t diag = k ? Hg[k - 1] : ldiag;
             const uint32_t ne = pk_min_u16(tc ^ qc[k], one2);  // 1 where the symbols differ
-            const uint32_t d = pk_mad_u16(ne, negdelta2, diag + mg2);
-            const uint32_t m = pk_max_u16(pk_max_u16(d, up), left);
-            const uint32_t signs = __builtin_amdgcn_perm(pk_sub_u16(d, m), pk_sub_u16(left, m), 0x0B0A0908u);
+            dc[k] = pk_mad_u16(ne, negdelta2, diag + mg2);
+            mx[k] = pk_max_u16(dc[k], Hg[k]);
+          }
+          // pass 2: the dependent chain along the row (max with the left candidate, then + gap), with the
+          // flag work of the cell before interleaved so that the chain's latencies are covered.  Flags:
+          // candidate - max is negative (bit 15 of the half set) exactly when the candidate is NOT the
+          // maximum; one v_perm turns the four sign bits into four 0x00/0xFF bytes.
+          uint32_t left = recv, acc0 = 0, acc1 = 0;
+          auto flags = [&](int k, uint32_t lin) __attribute__((always_inline)) {
+            const uint32_t signs =
+                __builtin_amdgcn_perm(pk_sub_u16(dc[k], mx[k]), pk_sub_u16(lin, mx[k]), 0x0B0A0908u);
             if (k < 8)
               acc0 = and_or(signs, 0x01010101u << (k & 7), acc0);
             else
               acc1 = and_or(signs, 0x01010101u << (k & 7), acc1);
-            diag = up;
-            left = m - gsub2;  // S(H[i][column] + gap)
+          };
+          uint32_t lin_prev = recv;
+#pragma unroll
+          for (int k = 0; k < C; ++k) {
+            const uint32_t lin = left;
+            mx[k] = pk_max_u16(mx[k], left);
+            left = mx[k] - gsub2;  // S(H[i][column] + gap)
             Hg[k] = left;
+            if (k > 0) flags(k - 1, lin_prev);
+            lin_prev = lin;
           }
+          flags(C - 1, lin_prev);
           drow[(uint64_t)st * 64] = make_uint2(acc0, acc1);
           ldiag = recv;
           lastcol = left;
