@@ -176,24 +176,37 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
       const int recv = lane == 0 ? first : from_left;
       const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
       if (FULL || (st > lane && i <= T)) {
-        int diag = ldiag, left = recv;
-        uint32_t acc = 0, rowkey = 0;
+        // pass 1 (no dependencies between cells): diagonal candidates from the previous row's values
+        // still held in Hg, already maximised with the "up" candidate (and with 0 for Local)
+        int dc[C], mx[C];
 #pragma unroll
         for (int k = 0; k < C; ++k) {
-          const int up = Hg[k];
-          const int d = diag + (tc == qc[k] ? em : ex);
-          int m = max3i(d, up, left);
-          if (MODE == SA_LOCAL) m = max(m, 0);
-          acc = shift_in_sign(acc, d - m);
-          acc = shift_in_sign(acc, left - m);
+          const int diag = k ? Hg[k - 1] : ldiag;
+          dc[k] = diag + (tc == qc[k] ? em : ex);
+          mx[k] = (MODE == SA_LOCAL) ? max3i(dc[k], Hg[k], 0) : max(dc[k], Hg[k]);
+        }
+        // pass 2: the dependent chain along the row (max with the left candidate, then + gap), with the
+        // flag work of the cell before interleaved so that the chain's latencies are covered
+        int left = recv, lin_prev = recv;
+        uint32_t acc = 0, rowkey = 0;
+        auto flags = [&](int k, int lin) __attribute__((always_inline)) {
+          acc = shift_in_sign(acc, dc[k] - mx[k]);
+          acc = shift_in_sign(acc, lin - mx[k]);
           if (MODE == SA_LOCAL) {  // leftmost maximum of the row: larger score, then smaller k
-            const uint32_t key = ((uint32_t)m << 4) + (uint32_t)(15 - k);
+            const uint32_t key = ((uint32_t)mx[k] << 4) + (uint32_t)(15 - k);
             rowkey = key > rowkey ? key : rowkey;
           }
-          diag = up;
-          left = m + gap;
+        };
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const int lin = left;
+          mx[k] = max(mx[k], left);
+          left = mx[k] + gap;
           Hg[k] = left;
+          if (k > 0) flags(k - 1, lin_prev);
+          lin_prev = lin;
         }
+        flags(C - 1, lin_prev);
         drow[(uint64_t)st * 64] = (word_t)acc;
         ldiag = recv;
         lastcol = left;
