@@ -165,6 +165,13 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above and the query symbols
     const uint32_t steps = T + 63;
     word_t* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
+    // stores the boundary rows gathered in bout: rows row - slot .. row, tagged with this strip
+    auto publish = [&](uint32_t row, uint32_t slot) __attribute__((always_inline)) {
+      const uint32_t base = row - slot;
+      if (base + lane <= row)
+        __hip_atomic_store(&bout_p[base + lane], ((uint64_t)(s + 1) << 32) | (uint32_t)bout,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     // One step.  FULL: every lane has a valid row (64 <= st <= T), nothing is predicated.
     auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_tag)::value;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
       const int tc = tc_next;
       tc_next = (int)tring[(st - lane) & 255u];  // position of row st + 1 - lane
       const int from_left = dpp_from_lane_below(lastcol);
-      const int first = (s == 0) ? border_col0<MODE>((int)st, gap) + gap : __builtin_amdgcn_readlane(bnext, j);
+      const int first = __builtin_amdgcn_readlane(bnext, j);  // column c0 of lane 0: border or previous strip
       const int recv = lane == 0 ? first : from_left;
       const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
       if (FULL || (st > lane && i <= T)) {
@@ -233,17 +240,13 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
         }
       }
       // lane 63 finished row st - 63 of the strip's last column: collect 64 of them, store coalesced
+      // (in a full batch the store falls on the batch's last step but one: done by the caller)
       if (!last_strip && (FULL || st >= 64)) {
         const int v63 = __builtin_amdgcn_readlane(lastcol, 63);
         const uint32_t row = st - 63;  // 1 ..
         const uint32_t slot = (row - 1) & 63;
         bout = lane == slot ? v63 : bout;
-        if (slot == 63 || row == T) {
-          const uint32_t base = row - slot;  // first row held in bout
-          if (base + lane <= row)
-            __hip_atomic_store(&bout_p[base + lane], ((uint64_t)(s + 1) << 32) | (uint32_t)bout,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (!FULL && (slot == 63 || row == T)) publish(row, slot);
       }
     };
     for (uint32_t b0 = 1; b0 <= steps; b0 += 64) {  // batches of 64 steps
@@ -268,10 +271,14 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
           }
         }
         bnext = (int)(uint32_t)e;
+      } else {  // column 0 of the matrix
+        bnext = border_col0<MODE>((int)(b0 + lane), gap) + gap;
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, so that no step has to wait on it
       if (b0 >= 64 && b0 + 63 <= T) {
-        for (uint32_t x = 0; x < 64; ++x) step(b0 + x, std::true_type{});
+        for (uint32_t x = 0; x < 63; ++x) step(b0 + x, std::true_type{});
+        if (!last_strip) publish(b0 - 1, 63);  // rows b0-64 .. b0-1 are complete after step b0+62
+        step(b0 + 63, std::true_type{});
       } else {
         const uint32_t e = b0 + 63 < steps ? b0 + 63 : steps;
         for (uint32_t st = b0; st <= e; ++st) step(st, std::false_type{});
