@@ -217,3 +217,21 @@ def test_cooperative_single_long_pair_vs_oracle(oracle):
         b = align.DeviceAlignBatch([q], [t], typ, m, x, g)
         assert b.kernel_name() == "wave_i32_coop"
         _run_group(cases)
+
+
+def test_empty_and_odd_batches_vs_oracle(oracle, family):
+    """Empty queries / targets next to ordinary pairs, and batches of 1 and 3 pairs (a packed wavefront or
+    lane then holds a pair without a partner); the meaning of the empty cases is the one the CPU
+    restatement fixes (the reference itself reads out of bounds there)."""
+    from sequencealigner_amd import align
+    rng = random.Random(17)
+    def rnd(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    base = [("", "ACGT"), ("ACGT", ""), ("", ""), (rnd(70), rnd(90)), ("", rnd(300)), (rnd(300), ""),
+            (rnd(1100), rnd(1300)), (rnd(5), rnd(2000)), (rnd(2100), rnd(7))]
+    for pairs in (base, base[3:4], base[:3], base[5:8]):
+        for typ in (0, 1, 2):
+            want = [oracle.align(q, t, typ, 1, -1, -1) for q, t in pairs]
+            scores, cigars, tb = align.align_batch([q for q, _ in pairs], [t for _, t in pairs], typ, 1, -1, -1)
+            got = [(int(s_), c_, int(b_)) for s_, c_, b_ in zip(scores, cigars, tb)]
+            assert got == want, (typ, family, [(len(q), len(t)) for q, t in pairs])
