@@ -443,7 +443,6 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
                                                        uint32_t* tile_count, uint32_t key_shift,
                                                        uint32_t value_bits) {
   __shared__ uint64_t grouped[kSmallMax];
-  __shared__ uint64_t ordered[kSmallMax];
   __shared__ uint32_t bins[kBins];
   __shared__ uint32_t lds[kThreads / 64];
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
@@ -504,12 +503,11 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
       rank += (other < key || same_before) ? 1u : 0u;
       dup |= same_before;
     }
-    ordered[lo + rank] = key;
+    sorted[begin + lo + rank] = key;
     uniq += dup ? 0u : 1u;
   }
   uint32_t unused;
-  const uint32_t total = block_sum(uniq, lds, &unused);  // (synchronises the block)
-  for (uint32_t p = tid; p < count; p += kThreads) sorted[begin + p] = ordered[p];
+  const uint32_t total = block_sum(uniq, lds, &unused);
   if (tid == 0) tile_count[tile_base[s]] = total;
 }
 
