@@ -350,6 +350,7 @@ struct UniqArgs {
   const uint32_t* tile_base;  // n + 1: first tile of every sequence
   uint32_t n;
   uint32_t skip_small;        // uniq_count: tiles of sequences with <= kSmallMax keys are already counted
+  const uint32_t* n_big;      // uniq_count: sequences left to the segmented sort (skip_small only)
   uint32_t* tile_count;       // per tile: keys that differ from their predecessor
   const uint64_t* tile_off;   // exclusive scan of tile_count
   uint32_t key_shift;
@@ -441,14 +442,17 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
                                                        const uint32_t* seg_begin, const uint32_t* seg_end,
                                                        uint32_t* big_end, const uint32_t* tile_base,
                                                        uint32_t* tile_count, uint32_t key_shift,
-                                                       uint32_t value_bits) {
+                                                       uint32_t value_bits, uint32_t* n_big) {
   __shared__ uint64_t grouped[kSmallMax];
   __shared__ uint32_t bins[kBins];
   __shared__ uint32_t lds[kThreads / 64];
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   const uint32_t begin = seg_begin[s], count = seg_end[s] - begin;
   if (count > kSmallMax || count == 0) {
-    if (tid == 0) big_end[s] = seg_end[s];
+    if (tid == 0) {
+      big_end[s] = seg_end[s];
+      if (count) atomicAdd(n_big, 1u);
+    }
     return;
   }
   if (tid == 0) big_end[s] = begin;
@@ -513,6 +517,7 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
 
 __global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
   __shared__ uint32_t lds[kThreads / 64];
+  if (u.skip_small && *u.n_big == 0) return;  // every tile was counted by sort_small
   const uint32_t tiles = u.tile_base[u.n];
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     uint32_t begin, end, seg_first;
@@ -629,7 +634,7 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_chunk_base = take(n1);
   pl->o_windows = take(n1);
   pl->o_wbase = take(n1);
-  pl->o_counter = take(n1);      // n counters + the count of unresolved chunks
+  pl->o_counter = take(n1 + 4);  // n counters, the count of unresolved chunks, the count of long sequences
   pl->o_exit_f = take(mc * 4);
   pl->o_exit_c = take(mc * 4);
   pl->o_resolved = take(mc);
@@ -698,6 +703,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   uint32_t* wbase = (uint32_t*)(ws + pl.o_wbase);
   uint32_t* counter = (uint32_t*)(ws + pl.o_counter);
   uint32_t* n_unresolved = counter + b->n;
+  uint32_t* n_big = counter + b->n + 1;
   uint64_t* keys = (uint64_t*)(ws + pl.o_keys);
   uint64_t* sorted = (uint64_t*)(ws + pl.o_sorted);
   uint32_t* seg_begin = (uint32_t*)(ws + pl.o_seg_begin);
@@ -726,7 +732,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.keys = keys;
   a.status = b->d_status;
   if (b->d_status) SA_HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), stream));
-  SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 1) * 4, stream));
+  SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 2) * 4, stream));
   SA_HIP_TRY(hipMemsetAsync(tile_count, 0, ((size_t)pl.max_tiles + 1) * 4, stream));
 
   auto blocks = [](uint64_t items) { return dim3((unsigned)((items + kThreads - 1) / kThreads)); };
@@ -762,7 +768,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
       SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
   } else {
     hipLaunchKernelGGL(sort_small, dim3(b->n), dim3(kThreads), 0, stream, keys, sorted, seg_begin, seg_end,
-                       big_end, tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift);
+                       big_end, tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift, n_big);
     SA_HIP_TRY(hipGetLastError());
     if (!all_small)
       SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
@@ -775,6 +781,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   u.tile_base = tile_base;
   u.n = b->n;
   u.skip_small = b->n > 1;
+  u.n_big = n_big;
   u.tile_count = tile_count;
   u.tile_off = tile_off;
   u.key_shift = pl.key_shift;
