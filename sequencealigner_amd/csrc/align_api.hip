@@ -52,6 +52,7 @@ struct Plan {
   bool coop;                  // wavefront kernels: one wave per (pair, strip), all resident
   bool wave_pk;               // wavefront kernels: packed 16-bit scores, two pairs per wave
   size_t bytes_per_block;     // workspace bytes per workgroup (4 units)
+  uint32_t units_per_block;   // wavefronts per workgroup (the workspace is laid out per workgroup)
   uint32_t pairs_per_block;
   const char* name;
 };
@@ -192,7 +193,8 @@ Plan make_plan(const sa_align_batch& b) {
     pl.dirs_unit_stride = (uint64_t)pl.nstrips * max_q * (kLaneI32K / 16) * 64;
     pl.brow_unit_stride = (uint64_t)(max_q + 1) * 64;
   }
-  const size_t units = kBlock / 64;
+  const size_t units = pl.family == Family::WaveI32 ? 1 : kBlock / 64;  // wavefront kernels: 64-thread groups
+  pl.units_per_block = (uint32_t)units;
   pl.pairs_per_block = (uint32_t)units * pl.pairs_per_unit;
   pl.bytes_per_block = round_up(units * pl.dirs_unit_stride * 4, 256) +
                        round_up(units * pl.brow_unit_stride * 4, 256) +
@@ -433,7 +435,7 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   const size_t total_blocks = ((size_t)b->n + pl.pairs_per_block - 1) / pl.pairs_per_block;
   size_t blocks_per_pass = (workspace_bytes - kFixedWorkspace) / pl.bytes_per_block;
   if (blocks_per_pass > total_blocks) blocks_per_pass = total_blocks;
-  const size_t units_per_pass = blocks_per_pass * (kBlock / 64);
+  const size_t units_per_pass = blocks_per_pass * pl.units_per_block;
   size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 
   // carve the workspace
