@@ -415,11 +415,15 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
 }
 
 // Traceback + run-length encoding for the tiled layout above, one pair per thread; same rules as
-// traceback_kernel (align_common.h).  The thread keeps the current 64-byte direction segment and 8
-// symbols of each sequence in registers, so a path of ~(Q+T) steps costs ~(Q+T)/8 memory round trips.
+// traceback_kernel (align_common.h).  The thread keeps the current 64-byte direction segment in LDS (one
+// dword read per step) and 8 symbols of each sequence in registers, so a path of ~(Q+T) steps costs
+// ~(Q+T)/8 memory round trips.  The step itself is written without branches (the 64 paths of a wave
+// diverge at every step): the move is decoded into "consumes a row" / "consumes a column" flags.
 template <int MODE, int K>
 __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   constexpr int NG = LanePk16Geom<K>::NG;
+  constexpr uint32_t kSegStride = 17;  // dwords per thread in LDS: 16 + 1, conflict-free across lanes
+  __shared__ uint32_t seg[256 * kSegStride];
   const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
   if (pl >= a.pairs_in_pass) return;
   const uint32_t p = a.pair_base + pl;
@@ -432,13 +436,13 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   const uint32_t unit = pl >> 7, lane = pl & 63, half = (pl >> 6) & 1;
   const uint32_t nrb = LanePk16Tiles<K>::col_blocks(a.max_q);
   const uint32_t* dirs = a.dirs + (uint64_t)unit * a.dirs_unit_stride + lane * 16;
+  uint32_t* myseg = seg + threadIdx.x * kSegStride;
 
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
 
   uint32_t cached_tile = 0xFFFFFFFFu;
-  uint4 seg0 = make_uint4(0, 0, 0, 0), seg1 = seg0, seg2 = seg0, seg3 = seg0;
   // 8-symbol windows of the sequences: bytes [base, base + 8) of the blob, base 8-byte aligned
   uint64_t qwin_base = ~0ull, twin_base = ~0ull;
   uint64_t qwin = 0, twin = 0;
@@ -446,36 +450,32 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
-    if (MODE == SA_LOCAL && remaining == 0) break;
-    uint32_t d;
-    if (i == 0 || r == 0) {
-      d = border_dir<MODE>(i, r, a.gap);
-    } else {
-      const uint32_t s = (i - 1) / K, k = (i - 1) % K;
-      const uint32_t g = k >> 4, j = k & 15;
-      const uint32_t tile = (s * nrb + (r - 1) / kColBlock) * NG + g;
-      if (tile != cached_tile) {
-        const uint4* src = reinterpret_cast<const uint4*>(dirs + (uint64_t)tile * 1024);
-        seg0 = src[0];
-        seg1 = src[1];
-        seg2 = src[2];
-        seg3 = src[3];
-        cached_tile = tile;
-      }
-      const uint32_t c = (r - 1) & (kColBlock - 1);
-      const uint4 sel = (c < 4) ? ((c < 2) ? seg0 : seg1) : ((c < 6) ? seg2 : seg3);
-      // per column a lane stores two dwords: rows 0-7 and rows 8-15 of the group; byte 2+half holds the
-      // "diagonal candidate is not the maximum" bits, byte half the "left candidate is not" bits
-      const uint32_t w0 = (c & 1) ? sel.z : sel.x, w1 = (c & 1) ? sel.w : sel.y;
-      const uint32_t word = (j < 8) ? w0 : w1;
-      const uint32_t not_diag = (word >> (16 + 8 * half + (j & 7))) & 1u;
-      const uint32_t not_left = (word >> (8 * half + (j & 7))) & 1u;
-      d = !not_diag ? DIR_DIAG : (!not_left ? DIR_LEFT : DIR_UP);
+    // Local (gap < 0 here): the borders are None, and an inner cell with score 0 is None
+    if (MODE == SA_LOCAL && (remaining == 0 || i == 0 || r == 0)) break;
+    const bool interior = i != 0 && r != 0;
+    const uint32_t ii = interior ? i - 1 : 0, rr = interior ? r - 1 : 0;
+    const uint32_t s = ii / K, k = ii - s * K;
+    const uint32_t g = k >> 4, j = k & 15;
+    const uint32_t tile = (s * nrb + (rr >> 3)) * NG + g;
+    if (interior && tile != cached_tile) {
+      const uint4* src = reinterpret_cast<const uint4*>(dirs + (uint64_t)tile * 1024);
+      const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+      myseg[0] = v0.x; myseg[1] = v0.y; myseg[2] = v0.z; myseg[3] = v0.w;
+      myseg[4] = v1.x; myseg[5] = v1.y; myseg[6] = v1.z; myseg[7] = v1.w;
+      myseg[8] = v2.x; myseg[9] = v2.y; myseg[10] = v2.z; myseg[11] = v2.w;
+      myseg[12] = v3.x; myseg[13] = v3.y; myseg[14] = v3.z; myseg[15] = v3.w;
+      cached_tile = tile;
     }
-    if (d == DIR_NONE) break;
-    uint32_t op;
-    if (d == DIR_DIAG) {
-      const uint64_t qa = qb + (r - 1), ta = tb0 + (i - 1);
+    // per column a lane stores two dwords: rows 0-7 and rows 8-15 of the group; byte 2+half holds the
+    // "diagonal candidate is not the maximum" bits, byte half the "left candidate is not" bits
+    const uint32_t word = myseg[2 * (rr & 7) + (j >> 3)] >> (8 * half + (j & 7));
+    const bool not_left = word & 1u, not_diag = (word >> 16) & 1u;
+    // border cells (Global / Semiglobal only get here): row 0 moves Left, column 0 moves Up
+    const bool is_diag = interior && !not_diag;
+    const bool is_left = interior ? (not_diag && !not_left) : (i == 0);
+    bool eq = false;
+    if (is_diag) {
+      const uint64_t qa = qb + rr, ta = tb0 + ii;
       if ((qa & ~7ull) != qwin_base) {
         qwin_base = qa & ~7ull;
         qwin = *reinterpret_cast<const uint64_t*>(a.q + qwin_base);
@@ -484,20 +484,12 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
         twin_base = ta & ~7ull;
         twin = *reinterpret_cast<const uint64_t*>(a.t + twin_base);
       }
-      const bool eq = ((qwin >> (8 * (qa & 7))) & 0xFF) == ((twin >> (8 * (ta & 7))) & 0xFF);
-      op = (same || eq) ? SA_OP_M : SA_OP_X;
-      if (MODE == SA_LOCAL) remaining -= eq ? a.match : a.mismatch;
-      --i;
-      --r;
-    } else if (d == DIR_LEFT) {
-      op = SA_OP_I;
-      if (MODE == SA_LOCAL) remaining -= a.gap;
-      --r;
-    } else {
-      op = SA_OP_D;
-      if (MODE == SA_LOCAL) remaining -= a.gap;
-      --i;
+      eq = ((uint32_t)(qwin >> (8 * (qa & 7))) & 0xFFu) == ((uint32_t)(twin >> (8 * (ta & 7))) & 0xFFu);
     }
+    const uint32_t op = is_diag ? ((same || eq) ? SA_OP_M : SA_OP_X) : (is_left ? SA_OP_I : SA_OP_D);
+    if (MODE == SA_LOCAL) remaining -= is_diag ? (eq ? a.match : a.mismatch) : a.gap;
+    i -= (is_diag || !is_left) ? 1u : 0u;
+    r -= (is_diag || is_left) ? 1u : 0u;
     if (op == cur_op) {
       ++cur_len;
     } else {
