@@ -120,6 +120,18 @@ const char* sa_align_kernel_name(const sa_align_batch* batch);
 int sa_align_profile(int enable);
 int sa_align_profile_read(double ms[3], uint64_t launches[3]);
 
+/* CIGAR statistics on the device, for the PAF columns the reference's mapper derives from every
+ * alignment (getAlignmentBlockLengthAndMatchLength, reference src/mapper.cpp:371-399, called at :428
+ * and printed by generatePAFString, :354-369): d_block_len[p] = sum of all run lengths (the mapper's
+ * "alignment block length"); d_op_len[4*p + op] = total length of the runs of op (SA_OP_M, _X, _I, _D).
+ * The mapper's own "match length" looks for a lower-case 'm' (:392) that CompressCigar never prints and
+ * is therefore always 0; d_op_len[4*p + SA_OP_M] is the number a corrected caller would want.
+ * d_cigar_runs / d_cigar_nruns / cigar_stride are the arrays sa_align_batch_device filled; either
+ * output may be NULL. */
+int sa_cigar_stats_device(int device, void* stream, uint32_t n, const uint32_t* d_cigar_runs,
+                          const uint32_t* d_cigar_nruns, uint64_t cigar_stride, uint32_t* d_block_len,
+                          uint32_t* d_op_len);
+
 /* ---------------------------------------------------------------------------------------------
  * Alignment, host buffers.  The device batch queue: pairs are split over `n_devices` GPUs
  * (0 = all visible) by cost (query_len * target_len), staged through pinned buffers, aligned on each

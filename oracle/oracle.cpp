@@ -447,6 +447,27 @@ int sa_cpu_minimize_batch(const char* blob, const uint64_t* off, const uint32_t*
   return 0;
 }
 
+// mapper.cpp:371-399: digits accumulate into `value`; the first non-digit after a number adds it to the
+// block length; an 'm' adds the current value to the match length.
+void sa_cpu_cigar_block_match(const char* cigar, int* abl, int* ml) {
+  int value = 0, sum = 0, match = 0;
+  bool in_number = false;
+  for (const char* c = cigar; *c; ++c) {
+    if (*c >= '0' && *c <= '9') {
+      value = in_number ? value * 10 + (*c - '0') : (*c - '0');
+      in_number = true;
+    } else {
+      if (in_number) {
+        sum += value;
+        in_number = false;
+      }
+      if (*c == 'm') match += value;
+    }
+  }
+  *abl = sum;
+  *ml = match;
+}
+
 const char* sa_cpu_kind(void) { return "restatement"; }
 
 }  // extern "C"

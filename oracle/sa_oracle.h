@@ -59,6 +59,12 @@ int sa_cpu_minimize_batch(const char* blob, const uint64_t* off, const uint32_t*
                           uint32_t kmer_len, uint32_t window_len, int threads, uint64_t* counts);
 
 /* "restatement" or "reference" */
+/* Restates getAlignmentBlockLengthAndMatchLength (reference src/mapper.cpp:371-399): *abl = sum of the
+ * CIGAR's counts, *ml = sum of the counts in front of a LOWER-case 'm' (which CompressCigar never
+ * prints: the reference's own match length is always 0 on its own CIGARs).  That function is static
+ * inside mapper.cpp, which cannot be built here (un-vendored dependencies): parity unpinned. */
+void sa_cpu_cigar_block_match(const char* cigar, int* abl, int* ml);
+
 const char* sa_cpu_kind(void);
 
 #ifdef __cplusplus

@@ -114,6 +114,20 @@ class DeviceAlignBatch:
     def target_begins(self):
         return self.d_tb[:self.n].cpu().numpy().view(np.uint32)
 
+    def cigar_stats(self, stream=None):
+        """(alignment block length, per-op lengths [n, 4] in the order M X I D) of every pair, computed
+        on the device from the run arrays - the sums the reference's mapper takes from the CIGAR text
+        (getAlignmentBlockLengthAndMatchLength, src/mapper.cpp:371-399)."""
+        import torch
+        block = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.device)
+        ops = torch.zeros(max(self.n, 1) * 4, dtype=torch.int32, device=self.device)
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        capi.check(self.lib.sa_cigar_stats_device(self.device.index or 0, s.cuda_stream, self.n,
+                                                  self.d_runs.data_ptr(), self.d_nruns.data_ptr(), self.stride,
+                                                  block.data_ptr(), ops.data_ptr()))
+        s.synchronize()
+        return block[:self.n].cpu().numpy(), ops[:self.n * 4].cpu().numpy().reshape(self.n, 4)
+
     def cigars(self, indices=None):
         """CIGAR strings of the given pairs (default: all)."""
         nruns = self.d_nruns[:self.n].cpu().numpy()

@@ -52,6 +52,8 @@ SYMBOLS = [
     ("sa_align_kernel_name", C.c_char_p, [C.POINTER(AlignBatch)]),
     ("sa_align_profile", C.c_int, [C.c_int]),
     ("sa_align_profile_read", C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    ("sa_cigar_stats_device", C.c_int,
+     [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("sa_align_batch_host", C.c_int,
      [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
       C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),

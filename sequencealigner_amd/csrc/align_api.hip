@@ -233,6 +233,33 @@ struct Timed {
   }
 };
 
+// One wavefront per pair sums the pair's run lengths per op (reference src/mapper.cpp:371-399 walks the
+// CIGAR text for the same sums).
+__global__ __launch_bounds__(256) void cigar_stats_kernel(uint32_t n, const uint32_t* runs, const uint32_t* nruns,
+                                                          uint64_t stride, uint32_t* block_len, uint32_t* op_len) {
+  const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (p >= n) return;
+  const uint32_t nr = nruns[p];
+  const uint32_t* first = runs + (uint64_t)(p + 1) * stride - nr;  // runs end at the end of the slot range
+  uint32_t sum[4] = {0, 0, 0, 0};
+  for (uint32_t x = lane; x < nr; x += 64) {
+    const uint32_t run = first[x];
+#pragma unroll
+    for (uint32_t op = 0; op < 4; ++op) sum[op] += (run & 3u) == op ? run >> 2 : 0u;
+  }
+#pragma unroll
+  for (uint32_t op = 0; op < 4; ++op)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum[op] += (uint32_t)__shfl_xor((int)sum[op], off);
+  if (lane == 0) {
+    if (block_len) block_len[p] = sum[0] + sum[1] + sum[2] + sum[3];
+    if (op_len) {
+#pragma unroll
+      for (uint32_t op = 0; op < 4; ++op) op_len[4 * (uint64_t)p + op] = sum[op];
+    }
+  }
+}
+
 template <int MODE>
 int launch_lane_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback) {
   const uint32_t blocks = (a.pairs_in_pass + kBlock - 1) / kBlock;
@@ -396,6 +423,18 @@ int sa_align_profile_read(double ms[3], uint64_t launches[3]) {
     (void)hipEventDestroy(sp.b);
   }
   g_spans.clear();
+  return SA_OK;
+}
+
+int sa_cigar_stats_device(int device, void* stream, uint32_t n, const uint32_t* d_cigar_runs,
+                          const uint32_t* d_cigar_nruns, uint64_t cigar_stride, uint32_t* d_block_len,
+                          uint32_t* d_op_len) {
+  if (n == 0) return SA_OK;
+  if (!d_cigar_runs || !d_cigar_nruns) return fail(SA_ERR_ARGUMENT, "NULL run arrays");
+  SA_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(cigar_stats_kernel, dim3((unsigned)(((uint64_t)n * 64 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, d_cigar_runs, d_cigar_nruns, cigar_stride, d_block_len, d_op_len);
+  SA_HIP_TRY(hipGetLastError());
   return SA_OK;
 }
 

@@ -33,6 +33,9 @@ class CpuChecker:
         L.sa_cpu_minimize_batch.restype = C.c_int
         L.sa_cpu_minimize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        if hasattr(L, "sa_cpu_cigar_block_match"):
+            L.sa_cpu_cigar_block_match.restype = None
+            L.sa_cpu_cigar_block_match.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.sa_cpu_kind.restype = C.c_char_p
         self.kind = L.sa_cpu_kind().decode()
 
@@ -79,6 +82,12 @@ class CpuChecker:
         out = np.zeros_like(a)
         n = self.lib.sa_cpu_remove_duplicate(a.ctypes.data, a.shape[0], out.ctypes.data)
         return [tuple(int(x) for x in r) for r in a], [tuple(int(x) for x in r) for r in out[:n]]
+
+    def cigar_block_match(self, cigar):
+        """(alignment block length, match length) as the reference's mapper computes them from CIGAR text."""
+        abl, ml = C.c_int(0), C.c_int(0)
+        self.lib.sa_cpu_cigar_block_match(cigar.encode(), C.byref(abl), C.byref(ml))
+        return abl.value, ml.value
 
     def align_batch(self, q_blob, q_off, t_blob, t_off, type_, match, mismatch, gap, want_cigar,
                     threads):

@@ -235,3 +235,23 @@ def test_empty_and_odd_batches_vs_oracle(oracle, family):
             scores, cigars, tb = align.align_batch([q for q, _ in pairs], [t for _, t in pairs], typ, 1, -1, -1)
             got = [(int(s_), c_, int(b_)) for s_, c_, b_ in zip(scores, cigars, tb)]
             assert got == want, (typ, family, [(len(q), len(t)) for q, t in pairs])
+
+
+def test_cigar_stats_on_device_vs_text(oracle):
+    """Block length and per-op lengths from the run arrays equal what the mapper's text walk gives
+    (block length) and a plain count over the CIGAR text (per op)."""
+    import re
+    import torch
+    from sequencealigner_amd import align, synth
+    q, t = synth.pairs_short_read_window(3000, seed=41)
+    for typ in (0, 1, 2):
+        b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1)
+        b.run()
+        torch.cuda.synchronize()
+        block, ops = b.cigar_stats()
+        cigars = b.cigars()
+        for p in range(0, 3000, 13):
+            abl, ml = oracle.cigar_block_match(cigars[p])
+            assert (int(block[p]), ml) == (abl, 0)
+            want = [sum(int(n) for n, o in re.findall(r"(\d+)([MXID])", cigars[p]) if o == op) for op in "MXID"]
+            assert list(map(int, ops[p])) == want, cigars[p]
