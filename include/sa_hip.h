@@ -189,6 +189,37 @@ int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t
                            uint32_t w, int variant, int n_devices, uint32_t** out_triples,
                            uint64_t* out_counts);
 
+/* ---------------------------------------------------------------------------------------------
+ * Seed chaining, device-resident batch: what the reference's mapper does per read between
+ * MinimizeBinary and Align (reference src/mapper.cpp: getMinimizer :172-196 index,
+ * ignoreTooFrequentMinimizer :224-232, matchMinimizer :234-290, LongestIncreasingSubsequence :292-352,
+ * called from mapping() :410-419).
+ *
+ * d_ref: the reference's n_ref minimizer triples, d_reads / d_read_off: the reads' triples, both as
+ * sa_minimize_batch_device writes them (sorted by value, position, strand).  frequent_fraction is the
+ * mapper's -f: the (int)((int)distinct * f) reference values with the largest (occurrences, value) are
+ * ignored.  d_out[5*r ..] = {chain length, t_begin, t_end, q_begin, q_end} of read r: first / last
+ * reference and read positions on the longest chain of matches with strictly increasing reference
+ * positions (all 0 without a match; with a single match q_end = q_begin, where the reference leaves
+ * q_end uninitialised).  d_n_matches (optional): matched pairs per read.
+ * The number of matches decides the workspace: the call synchronises the stream once to read it, sets
+ * *needed_bytes (optional) and returns SA_ERR_WORKSPACE if the workspace is smaller - call again with a
+ * workspace of that size. */
+typedef struct sa_chain_batch {
+  const uint32_t* d_ref;
+  uint32_t n_ref;
+  float frequent_fraction;
+  const uint32_t* d_reads;
+  const uint64_t* d_read_off; /* n_reads + 1 entries */
+  uint32_t n_reads;
+  uint64_t n_read_triples; /* == read_off[n_reads] */
+  int32_t* d_out;
+  uint64_t* d_n_matches;
+} sa_chain_batch;
+
+int sa_chain_batch_device(int device, void* stream, const sa_chain_batch* batch, void* d_workspace,
+                          size_t workspace_bytes, size_t* needed_bytes);
+
 /* removeDuplicate on the device (reference src/utility.cpp:8-26): sorts n triples in place by
  * (value, position, strand) and writes the distinct ones to out (capacity n); *out_n = their number. */
 int sa_remove_duplicate_host(uint32_t* triples, size_t n, uint32_t* out, size_t* out_n);

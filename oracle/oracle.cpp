@@ -19,6 +19,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <tuple>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -466,6 +468,107 @@ void sa_cpu_cigar_block_match(const char* cigar, int* abl, int* ml) {
   }
   *abl = sum;
   *ml = match;
+}
+
+namespace {
+using SeedIndex = std::unordered_map<uint32_t, std::vector<std::pair<uint32_t, bool>>>;
+
+// mapper.cpp:172-196: append (position, strand) to the value's list, in list order
+SeedIndex build_index(const uint32_t* triples, size_t n) {
+  SeedIndex idx;
+  for (size_t x = 0; x < n; ++x) idx[triples[3 * x]].emplace_back(triples[3 * x + 1], triples[3 * x + 2] != 0);
+  return idx;
+}
+
+// mapper.cpp:198-205, 224-232
+void drop_frequent(SeedIndex& idx, float f) {
+  std::vector<std::tuple<int, uint32_t>> occ;
+  for (auto& kv : idx) occ.emplace_back((int)kv.second.size(), kv.first);
+  std::sort(occ.begin(), occ.end());
+  const int index = (int)occ.size() * f;  // (int)size, times a float, truncated
+  const int from = (int)occ.size() - index;
+  for (int i = from; i < (int)occ.size(); ++i) idx.erase(std::get<1>(occ[i]));
+}
+
+// mapper.cpp:234-290
+std::vector<std::tuple<uint32_t, uint32_t>> match_seeds(const SeedIndex& ref, const SeedIndex& frag) {
+  std::vector<std::tuple<uint32_t, uint32_t>> match;
+  for (auto& kv : frag) {
+    auto hit = ref.find(kv.first);
+    if (hit == ref.end()) continue;
+    std::vector<uint32_t> fo, fr, ro, rr;
+    for (auto& e : kv.second) (e.second ? fo : fr).push_back(e.first);
+    for (auto& e : hit->second) (e.second ? ro : rr).push_back(e.first);
+    std::sort(ro.begin(), ro.end());
+    std::sort(rr.begin(), rr.end());
+    for (uint32_t a : fo)
+      for (uint32_t b : ro) match.emplace_back(a, b);
+    for (uint32_t a : fr)
+      for (uint32_t b : rr) match.emplace_back(a, b);
+  }
+  std::sort(match.begin(), match.end());
+  return match;
+}
+
+// mapper.cpp:292-352
+int chain_lis(const std::vector<std::tuple<uint32_t, uint32_t>>& m, int& t_begin, int& t_end, int& q_begin,
+              int& q_end) {
+  const int n = (int)m.size();
+  const int INF = 1000000000;
+  if (n == 0) return 0;
+  if (n == 1) {
+    t_begin = t_end = (int)std::get<1>(m[0]);
+    q_begin = q_end = (int)std::get<0>(m[0]);  // (q_end: see the header)
+    return 1;
+  }
+  std::vector<int> parent(n + 1, INF), tails(n + 1, INF);
+  int length = 0;
+  for (int i = 0; i < n; ++i) {
+    int low = 1, high = length;
+    while (low <= high) {
+      const int mid = (low + high) / 2;  // ceil() of an integer quotient
+      if (std::get<1>(m[tails[mid]]) < std::get<1>(m[i]))
+        low = mid + 1;
+      else
+        high = mid - 1;
+    }
+    const int pos = low;
+    parent[i] = tails[pos - 1];
+    tails[pos] = i;
+    if (pos > length) length = pos;
+  }
+  std::vector<int> refs(length), frags(length);
+  int k = tails[length];
+  for (int j = length - 1; j >= 0; --j) {
+    refs[j] = (int)std::get<1>(m[k]);
+    frags[j] = (int)std::get<0>(m[k]);
+    k = parent[k];
+  }
+  t_begin = refs[0];
+  t_end = refs[length - 1];
+  q_begin = frags[0];
+  q_end = frags[length - 1];
+  return length;
+}
+}  // namespace
+
+void sa_cpu_chain_batch(const uint32_t* ref_triples, size_t n_ref, float f, const uint32_t* read_triples,
+                        const uint64_t* read_off, size_t n_reads, int32_t* out, uint64_t* n_matches) {
+  SeedIndex ref = build_index(ref_triples, n_ref);
+  drop_frequent(ref, f);
+  for (size_t r = 0; r < n_reads; ++r) {
+    const SeedIndex frag = build_index(read_triples + 3 * read_off[r], (size_t)(read_off[r + 1] - read_off[r]));
+    const auto m = match_seeds(ref, frag);
+    int tb = 0, te = 0, qb = 0, qe = 0;
+    const int len = chain_lis(m, tb, te, qb, qe);
+    int32_t* o = out + 5 * r;
+    o[0] = len;
+    o[1] = tb;
+    o[2] = te;
+    o[3] = qb;
+    o[4] = qe;
+    if (n_matches) n_matches[r] = m.size();
+  }
 }
 
 const char* sa_cpu_kind(void) { return "restatement"; }

@@ -65,6 +65,23 @@ int sa_cpu_minimize_batch(const char* blob, const uint64_t* off, const uint32_t*
  * inside mapper.cpp, which cannot be built here (un-vendored dependencies): parity unpinned. */
 void sa_cpu_cigar_block_match(const char* cigar, int* abl, int* ml);
 
+/* Seed chaining of reads against one reference, restating the mapper's own steps (reference
+ * src/mapper.cpp, static functions - that file cannot be built here, so this part is parity unpinned):
+ *   getMinimizer :172-196          index  value -> [(position, strand)] of a sorted minimizer list
+ *   ignoreTooFrequentMinimizer :224-232   drop the (int)((int)distinct * f) values with the largest
+ *                                  (occurrences, value)
+ *   matchMinimizer :234-290        all (read position, reference position) pairs of equal value and strand,
+ *                                  sorted by (read position, reference position)
+ *   LongestIncreasingSubsequence :292-352   strictly increasing reference positions; reports its length and
+ *                                  the first / last reference and read positions on it
+ * ref_triples / read_triples are (value, position, strand) lists as MinimizeBinary + removeDuplicate
+ * return them; read r owns triples [read_off[r], read_off[r+1]).  out[5*r ..] = {length, t_begin, t_end,
+ * q_begin, q_end}; with no match all five are 0 (the reference leaves its outputs untouched), with one
+ * match q_end = q_begin (the reference leaves q_end uninitialised, :302-308).  n_matches (optional)
+ * receives the number of matched pairs per read. */
+void sa_cpu_chain_batch(const uint32_t* ref_triples, size_t n_ref, float f, const uint32_t* read_triples,
+                        const uint64_t* read_off, size_t n_reads, int32_t* out, uint64_t* n_matches);
+
 const char* sa_cpu_kind(void);
 
 #ifdef __cplusplus

@@ -42,6 +42,12 @@ class MinimizeBatch(C.Structure):
 
 
 # every symbol include/sa_hip.h declares: (name, restype, argtypes)
+class ChainBatch(C.Structure):
+    _fields_ = [("d_ref", C.c_void_p), ("n_ref", C.c_uint32), ("frequent_fraction", C.c_float),
+                ("d_reads", C.c_void_p), ("d_read_off", C.c_void_p), ("n_reads", C.c_uint32),
+                ("n_read_triples", C.c_uint64), ("d_out", C.c_void_p), ("d_n_matches", C.c_void_p)]
+
+
 SYMBOLS = [
     ("sa_last_error", C.c_char_p, []),
     ("sa_device_count", C.c_int, []),
@@ -67,6 +73,8 @@ SYMBOLS = [
     ("sa_minimize_batch_host", C.c_int,
      [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int,
       C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("sa_chain_batch_device", C.c_int,
+     [C.c_int, C.c_void_p, C.POINTER(ChainBatch), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("sa_remove_duplicate_host", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
 ]

@@ -36,6 +36,10 @@ class CpuChecker:
         if hasattr(L, "sa_cpu_cigar_block_match"):
             L.sa_cpu_cigar_block_match.restype = None
             L.sa_cpu_cigar_block_match.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if hasattr(L, "sa_cpu_chain_batch"):
+            L.sa_cpu_chain_batch.restype = None
+            L.sa_cpu_chain_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_void_p]
         L.sa_cpu_kind.restype = C.c_char_p
         self.kind = L.sa_cpu_kind().decode()
 
@@ -82,6 +86,19 @@ class CpuChecker:
         out = np.zeros_like(a)
         n = self.lib.sa_cpu_remove_duplicate(a.ctypes.data, a.shape[0], out.ctypes.data)
         return [tuple(int(x) for x in r) for r in a], [tuple(int(x) for x in r) for r in out[:n]]
+
+    def chain_batch(self, ref_triples, read_triples, read_off, f):
+        """(chain length, t_begin, t_end, q_begin, q_end) per read and the matched pairs per read, as the
+        reference's mapper derives them from the minimizer lists."""
+        ref = np.ascontiguousarray(ref_triples, dtype=np.uint32)
+        rd = np.ascontiguousarray(read_triples, dtype=np.uint32)
+        off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        n = len(off) - 1
+        out = np.zeros((n, 5), dtype=np.int32)
+        nm = np.zeros(n, dtype=np.uint64)
+        self.lib.sa_cpu_chain_batch(ref.ctypes.data, len(ref), f, rd.ctypes.data, off.ctypes.data, n,
+                                    out.ctypes.data, nm.ctypes.data)
+        return out, nm
 
     def cigar_block_match(self, cigar):
         """(alignment block length, match length) as the reference's mapper computes them from CIGAR text."""

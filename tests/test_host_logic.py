@@ -60,3 +60,23 @@ def test_paf_line_layout():
     assert paf.paf_line("r", 10, -1, -1, "t", 20, -1, -1, 0, 0) == "r\t10\t-1\t-1\t + \tt\t20\t-1\t-1\t0\t0\t0\n"
     lines = paf.paf_lines(["a", "b"], [5, 6], [(0, 5, 10, 15), (1, 6, 20, 26)], "t", 100, [5, 7], ["5M", "3M2D2M"])
     assert lines[1] == "b\t6\t1\t6\t + \tt\t100\t20\t26\t0\t7\t0\t3M2D2M\n"
+
+
+def test_chain_restatement_hand_cases(oracle):
+    """Seed chaining (reference src/mapper.cpp:172-352), small hand-traced cases."""
+    import numpy as np
+    ref = np.array([[5, 100, 1], [7, 10, 1], [7, 50, 0], [7, 90, 1], [9, 200, 1]], dtype=np.uint32)
+    reads = np.array([[5, 30, 1], [7, 3, 1], [9, 60, 1],      # read 0
+                      [8, 1, 1],                               # read 1: no common value
+                      [7, 4, 0]], dtype=np.uint32)             # read 2: one match on the other strand
+    off = np.array([0, 3, 4, 5], dtype=np.uint64)
+    out, nm = oracle.chain_batch(ref, reads, off, 0.0)
+    # read 0: matches sorted by (read pos, ref pos): (3,10) (3,90) (30,100) (60,200); only the reference
+    # positions must increase, so all four chain
+    assert list(nm) == [4, 0, 1]
+    assert out[0].tolist() == [4, 10, 200, 3, 60]
+    assert out[1].tolist() == [0, 0, 0, 0, 0]
+    assert out[2].tolist() == [1, 50, 50, 4, 4]
+    # f = 0.4: (int)(3 * 0.4) = 1 value dropped: the one with the most occurrences (7)
+    out, nm = oracle.chain_batch(ref, reads, off, 0.4)
+    assert list(nm) == [2, 0, 0] and out[0].tolist() == [2, 100, 200, 30, 60]
