@@ -1,0 +1,55 @@
+"""The mapper's per-read pipeline on the GPU (minimizers -> chaining -> Global alignment -> PAF record)
+against the same pipeline composed from the CPU checker's pieces (reference src/mapper.cpp:401-444)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_records(oracle, ref, names, reads, k, w, f, match, mismatch, gap, cigar_needed):
+    from sequencealigner_amd import paf
+    ref_tr = oracle.minimize_binary_array(ref, k, w)
+    lists = [oracle.minimize_binary_array(r, k, w) for r in reads]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+    spans, _ = oracle.chain_batch(ref_tr, np.concatenate(lists), off, f)
+    out = []
+    for i, r in enumerate(reads):
+        lis, tb, te, qb, qe = (int(v) for v in spans[i])
+        if lis > 0 and te - tb < 100000 and cigar_needed and len(r) < 5000:
+            _, cigar, _ = oracle.align(r[qb:qe], ref[tb:te], 0, match, mismatch, gap)
+            abl, ml = oracle.cigar_block_match(cigar)
+            out.append(paf.paf_line(names[i], len(r), qb, qe, "ref", len(ref), tb, te, ml, abl, cigar))
+        elif (not cigar_needed) or te - tb >= 100000 or len(r) >= 5000:
+            out.append(paf.paf_line(names[i], len(r), qb, qe, "ref", len(ref), tb, te, lis * k, max(qe - qb, te - tb)))
+        else:
+            out.append(paf.paf_line(names[i], len(r), -1, -1, "ref", len(ref), -1, -1, 0, 0))
+    return out
+
+
+@pytest.mark.parametrize("cigar_needed", [True, False])
+def test_pipeline_records_vs_cpu_composition(oracle, cigar_needed):
+    from sequencealigner_amd import mapper, synth
+    rng = random.Random(3)
+    ref = bytes(synth.genome(120_000, seed=71)).decode()
+    reads, names = [], []
+    for i in range(150):
+        L = rng.choice([200, 800, 2500, 4800, 6000])
+        p = rng.randint(0, len(ref) - L)
+        s = list(ref[p:p + L])
+        for x in range(len(s)):
+            if rng.random() < 0.04:
+                s[x] = rng.choice("ACGT")
+        reads.append("".join(s))
+        names.append("read%d" % i)
+    reads.append(bytes(synth.genome(900, seed=72)).decode())   # unrelated read: no chain (or a chance one)
+    names.append("stranger")
+    # spans of a single match (q_end == q_begin) make an empty Global pair, which the reference cannot
+    # align (it indexes an empty string): such reads are outside the comparison
+    want = _cpu_records(oracle, ref, names, reads, 15, 5, 0.001, 1, -1, -1, cigar_needed)
+    got = mapper.map_reads("ref", ref.encode(), names, [r.encode() for r in reads], 15, 5, 0.001, 1, -1, -1,
+                           cigar_needed)
+    assert len(got) == len(want)
+    same = sum(g == w for g, w in zip(got, want))
+    assert got == want, (same, len(want))
