@@ -142,10 +142,13 @@ __global__ void read_segments(const uint64_t* read_off, uint32_t n_reads, const 
 }
 
 // ---- longest increasing subsequence, one thread per read (src/mapper.cpp:292-352) -----------------------
-// tails[len] = index of the match that ends the best subsequence of that length, parent[i] = its
-// predecessor; the read's slices of both arrays start at seg_begin[r] (+ r for tails: n + 1 entries).
+// tails[len] = index of the match that ends the best subsequence of that length (tailv[len] = its
+// reference position, so that a search step is one load), parent[i] = its predecessor; the read's slices
+// start at seg_begin[r] (+ r for tails / tailv: n + 1 entries).  A match beyond the current best end is
+// appended without a search - the search would end there too.
 __global__ void chain_lis(const uint64_t* sorted, const uint32_t* seg_begin, const uint32_t* seg_end,
-                          uint32_t n_reads, int32_t* parent_all, int32_t* tails_all, int32_t* out) {
+                          uint32_t n_reads, int32_t* parent_all, int32_t* tails_all, uint32_t* tailv_all,
+                          int32_t* out) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads) return;
   const uint64_t* mt = sorted + seg_begin[r];
@@ -163,22 +166,30 @@ __global__ void chain_lis(const uint64_t* sorted, const uint32_t* seg_begin, con
   }
   int32_t* parent = parent_all + seg_begin[r];
   int32_t* tails = tails_all + seg_begin[r] + r;
+  uint32_t* tailv = tailv_all + seg_begin[r] + r;
   const int32_t INF = 1000000000;
   tails[0] = INF;
   int length = 0;
+  uint32_t best_end = 0;  // tailv[length]
   for (int i = 0; i < n; ++i) {
     const uint32_t ref_i = (uint32_t)mt[i];
-    int low = 1, high = length;
-    while (low <= high) {
-      const int mid = (low + high) / 2;
-      if ((uint32_t)mt[tails[mid]] < ref_i)
-        low = mid + 1;
-      else
-        high = mid - 1;
+    int low = length + 1;
+    if (length != 0 && !(best_end < ref_i)) {
+      low = 1;
+      int high = length;
+      while (low <= high) {
+        const int mid = (low + high) / 2;
+        if (tailv[mid] < ref_i)
+          low = mid + 1;
+        else
+          high = mid - 1;
+      }
     }
     parent[i] = tails[low - 1];
     tails[low] = i;
+    tailv[low] = ref_i;
     if (low > length) length = low;
+    if (low == length) best_end = ref_i;
   }
   int k = tails[length];
   const uint64_t last = mt[k];
@@ -314,7 +325,8 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
     return at;
   };
   const size_t o_keys = take((total + 1) * 8), o_sorted = take((total + 1) * 8), o_parent = take((total + 1) * 4),
-               o_tails = take((total + b->n_reads + 1) * 4), o_sort_tmp = take(sort_tmp);
+               o_tails = take((total + b->n_reads + 1) * 4), o_tailv = take((total + b->n_reads + 1) * 4),
+               o_sort_tmp = take(sort_tmp);
   if (needed_bytes) *needed_bytes = o;
   if (workspace_bytes < o)
     return fail(SA_ERR_WORKSPACE, "workspace of %zu bytes is below the %zu needed for %llu matches",
@@ -331,7 +343,8 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
                                                   seg_begin, seg_end, 0u, 64u, stream));
   }
   hipLaunchKernelGGL(chain_lis, blocks(b->n_reads), dim3(kThreads), 0, stream, sorted, seg_begin, seg_end,
-                     b->n_reads, (int32_t*)(ws + o_parent), (int32_t*)(ws + o_tails), b->d_out);
+                     b->n_reads, (int32_t*)(ws + o_parent), (int32_t*)(ws + o_tails), (uint32_t*)(ws + o_tailv),
+                     b->d_out);
   SA_HIP_TRY(hipGetLastError());
   return SA_OK;
 }
