@@ -49,7 +49,8 @@ enum {
   SA_ERR_WORKSPACE = 3,    /* workspace too small */
   SA_ERR_NO_DEVICE = 4,    /* no usable GPU */
   SA_ERR_RANGE = 5,        /* decimal Minimize: k-mer value exceeds INT_MAX (reference throws from stoi) */
-  SA_ERR_CAPACITY = 6      /* an output buffer is too small */
+  SA_ERR_CAPACITY = 6,     /* an output buffer is too small */
+  SA_ERR_FORMAT = 7        /* a sequence file breaks the rules of its format */
 };
 
 const char* sa_last_error(void);
@@ -219,6 +220,59 @@ typedef struct sa_chain_batch {
 
 int sa_chain_batch_device(int device, void* stream, const sa_chain_batch* batch, void* d_workspace,
                           size_t workspace_bytes, size_t* needed_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sequence file ingest on the device: the bytes of a FASTA / FASTQ file, copied to device memory as they
+ * are, become the sequence blob + offsets the batch calls above read.  Takes the place of the parser calls
+ * in the reference's mapper (reference src/mapper.cpp:532-558, bioparser FastaParser / FastqParser filling
+ * Sequence{name, data, quality}, :21-37); host code no longer touches the bases.
+ *
+ * FASTA: a '>' outside a header line starts a record, its header runs to the next '\n', its name is the
+ * header up to the first white-space byte, its data are the non-white-space bytes up to the next record.
+ * FASTQ: four lines per record - '@' header, bases, '+' line, qualities (as many as bases); files that split
+ * a record's bases over several lines are rejected.  A file that breaks these rules (no leading '>', empty
+ * name, record without bases, ...) fails with SA_ERR_FORMAT where bioparser throws.
+ *
+ * d_file: n_bytes of file content, 16-byte aligned.  Outputs, all device pointers:
+ *   d_seq              the bases of all records back to back (16-byte aligned, seq_capacity bytes; n_bytes
+ *                      always suffices - add the 8 bytes of slack the batch calls want)
+ *   d_seq_off[r]       first byte of record r in d_seq; max_records + 1 entries, entry n_records = n_bases
+ *   d_name_start[r], d_name_len[r]   the record's name as a span of the file
+ *   d_qual_start[r]    FASTQ: first byte of the quality line in the file (its length is the record's)
+ * The call synchronises the stream (twice), then fills n_records, n_bases, min_len and max_len.  With
+ * n_records > max_records or n_bases > seq_capacity it returns SA_ERR_CAPACITY after setting n_records and
+ * n_bases, before writing any output: call again with larger buffers. */
+enum { SA_FMT_FASTA = 0, SA_FMT_FASTQ = 1 };
+
+typedef struct sa_ingest_batch {
+  const uint8_t* d_file;
+  uint64_t n_bytes;
+  int format; /* SA_FMT_FASTA / SA_FMT_FASTQ */
+  uint8_t* d_seq;
+  uint64_t seq_capacity;
+  uint64_t* d_seq_off;
+  uint64_t* d_name_start;
+  uint32_t* d_name_len;
+  uint64_t* d_qual_start; /* FASTQ only */
+  uint64_t max_records;
+  /* results */
+  uint64_t n_records;
+  uint64_t n_bases;
+  uint32_t min_len, max_len; /* shortest / longest record */
+} sa_ingest_batch;
+
+size_t sa_ingest_workspace_bytes(uint64_t n_bytes);
+int sa_ingest_device(int device, void* stream, sa_ingest_batch* batch, void* d_workspace, size_t workspace_bytes);
+
+/* Two bits per base, for keeping large read sets resident or shipping them over PCIe at a quarter of the
+ * size: base i of d_seq goes to bits 2*(i%32).. of d_packed[i/32] with the codes of the reference's mapNct
+ * (C 0, A 1, T 2, G 3 in either case, src/minimizer_binary.cpp:13-33); bit i%32 of d_other[i/32] is set where
+ * byte i is none of those.  Both arrays have (n_bases + 31) / 32 entries.  sa_unpack2bit_device is the
+ * inverse up to case: upper-case ACGT, 'N' where d_other is set.  d_seq must be 16-byte aligned. */
+int sa_pack2bit_device(int device, void* stream, const uint8_t* d_seq, uint64_t n_bases, uint64_t* d_packed,
+                       uint32_t* d_other);
+int sa_unpack2bit_device(int device, void* stream, const uint64_t* d_packed, const uint32_t* d_other,
+                         uint64_t n_bases, uint8_t* d_seq);
 
 /* removeDuplicate on the device (reference src/utility.cpp:8-26): sorts n triples in place by
  * (value, position, strand) and writes the distinct ones to out (capacity n); *out_n = their number. */

@@ -571,6 +571,105 @@ void sa_cpu_chain_batch(const uint32_t* ref_triples, size_t n_ref, float f, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sequence files -> records, the way the mapper's parser calls deliver them (reference
+// src/mapper.cpp:532-558 into Sequence{name, data, quality}, :21-37).  The parser itself is bioparser, a
+// git submodule the reference does not vendor, so this is a restatement of its documented behaviour and
+// PARITY UNPINNED: FASTA records start at a '>' outside a header line, the name is the header up to its
+// first white-space byte, the data are the non-white-space bytes up to the next record; FASTQ records are
+// four lines ('@' header, bases, '+' line, qualities of the same length).  Anything else is an error.
+namespace {
+bool blank(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+struct Record {
+  uint64_t name_start;
+  uint32_t name_len;
+  uint64_t qual_start;
+  std::string data;
+};
+
+uint32_t name_span(const uint8_t* file, uint64_t n, uint64_t from) {
+  uint64_t q = from;
+  while (q < n && !blank(file[q])) ++q;
+  return (uint32_t)(q - from);
+}
+
+bool parse_fasta(const uint8_t* file, uint64_t n, std::vector<Record>& recs) {
+  if (n == 0) return true;
+  if (file[0] != '>') return false;
+  uint64_t i = 0;
+  while (i < n) {
+    // at a '>' that opens a record
+    Record r;
+    r.name_start = i + 1;
+    r.name_len = name_span(file, n, i + 1);
+    r.qual_start = 0;
+    if (r.name_len == 0) return false;
+    while (i < n && file[i] != '\n') ++i;  // rest of the header line
+    while (i < n && file[i] != '>') {
+      if (!blank(file[i])) r.data.push_back((char)file[i]);
+      ++i;
+    }
+    if (r.data.empty()) return false;
+    recs.push_back(std::move(r));
+  }
+  return true;
+}
+
+bool parse_fastq(const uint8_t* file, uint64_t n, std::vector<Record>& recs) {
+  std::vector<std::pair<uint64_t, uint64_t>> lines;  // [begin, end) without the '\n'
+  uint64_t b = 0;
+  for (uint64_t i = 0; i < n; ++i)
+    if (file[i] == '\n') {
+      lines.emplace_back(b, i);
+      b = i + 1;
+    }
+  if (b < n) lines.emplace_back(b, n);
+  if (lines.size() % 4) return false;
+  auto stripped = [&](std::pair<uint64_t, uint64_t> l) {
+    std::string s;
+    for (uint64_t i = l.first; i < l.second; ++i)
+      if (!blank(file[i])) s.push_back((char)file[i]);
+    return s;
+  };
+  for (size_t l = 0; l < lines.size(); l += 4) {
+    Record r;
+    if (lines[l].first >= lines[l].second || file[lines[l].first] != '@') return false;
+    r.name_start = lines[l].first + 1;
+    r.name_len = name_span(file, n, r.name_start);
+    if (r.name_len == 0) return false;
+    r.data = stripped(lines[l + 1]);
+    if (r.data.empty()) return false;
+    if (lines[l + 2].first >= lines[l + 2].second || file[lines[l + 2].first] != '+') return false;
+    r.qual_start = lines[l + 3].first;
+    uint64_t qe = lines[l + 3].second;
+    while (qe > r.qual_start && blank(file[qe - 1])) --qe;
+    if (qe - r.qual_start != r.data.size()) return false;
+    recs.push_back(std::move(r));
+  }
+  return true;
+}
+}  // namespace
+
+int64_t sa_cpu_parse(const uint8_t* file, uint64_t n, int format, uint8_t* seq, uint64_t* seq_off,
+                     uint64_t* name_start, uint32_t* name_len, uint64_t* qual_start, uint64_t cap_records) {
+  std::vector<Record> recs;
+  const bool ok = format == 0 ? parse_fasta(file, n, recs) : parse_fastq(file, n, recs);
+  if (!ok) return -1;
+  if (recs.size() > cap_records) return -2;
+  uint64_t at = 0;
+  for (size_t r = 0; r < recs.size(); ++r) {
+    seq_off[r] = at;
+    memcpy(seq + at, recs[r].data.data(), recs[r].data.size());
+    at += recs[r].data.size();
+    name_start[r] = recs[r].name_start;
+    name_len[r] = recs[r].name_len;
+    if (qual_start) qual_start[r] = recs[r].qual_start;
+  }
+  seq_off[recs.size()] = at;
+  return (int64_t)recs.size();
+}
+
 const char* sa_cpu_kind(void) { return "restatement"; }
 
 }  // extern "C"

@@ -82,6 +82,15 @@ void sa_cpu_cigar_block_match(const char* cigar, int* abl, int* ml);
 void sa_cpu_chain_batch(const uint32_t* ref_triples, size_t n_ref, float f, const uint32_t* read_triples,
                         const uint64_t* read_off, size_t n_reads, int32_t* out, uint64_t* n_matches);
 
+/* FASTA (format 0) / FASTQ (format 1) file bytes -> records, as the mapper's parser calls deliver them
+ * (reference src/mapper.cpp:532-558; the parser is bioparser, which the reference does not vendor: a
+ * restatement of its documented rules, parity unpinned).  seq (capacity n) receives the bases of all records
+ * back to back, seq_off (cap_records + 1) their first bytes, name_start / name_len the names as spans of the
+ * file, qual_start (optional) the first byte of each FASTQ quality line.  Returns the number of records,
+ * -1 for a file that breaks the format, -2 if cap_records is too small. */
+int64_t sa_cpu_parse(const uint8_t* file, uint64_t n, int format, uint8_t* seq, uint64_t* seq_off,
+                     uint64_t* name_start, uint32_t* name_len, uint64_t* qual_start, uint64_t cap_records);
+
 const char* sa_cpu_kind(void);
 
 #ifdef __cplusplus

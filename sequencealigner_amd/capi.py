@@ -11,7 +11,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsa_hip.so")
 
 SA_GLOBAL, SA_LOCAL, SA_SEMIGLOBAL = 0, 1, 2
 SA_MIN_BINARY, SA_MIN_DECIMAL = 0, 1
-SA_OK, SA_ERR_HIP, SA_ERR_ARGUMENT, SA_ERR_WORKSPACE, SA_ERR_NO_DEVICE, SA_ERR_RANGE, SA_ERR_CAPACITY = range(7)
+(SA_OK, SA_ERR_HIP, SA_ERR_ARGUMENT, SA_ERR_WORKSPACE, SA_ERR_NO_DEVICE, SA_ERR_RANGE, SA_ERR_CAPACITY,
+ SA_ERR_FORMAT) = range(8)
+SA_FMT_FASTA, SA_FMT_FASTQ = 0, 1
 SA_UNKNOWN_TYPE_SCORE = 9999
 
 
@@ -48,6 +50,14 @@ class ChainBatch(C.Structure):
                 ("n_read_triples", C.c_uint64), ("d_out", C.c_void_p), ("d_n_matches", C.c_void_p)]
 
 
+class IngestBatch(C.Structure):
+    _fields_ = [("d_file", C.c_void_p), ("n_bytes", C.c_uint64), ("format", C.c_int), ("d_seq", C.c_void_p),
+                ("seq_capacity", C.c_uint64), ("d_seq_off", C.c_void_p), ("d_name_start", C.c_void_p),
+                ("d_name_len", C.c_void_p), ("d_qual_start", C.c_void_p), ("max_records", C.c_uint64),
+                ("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("min_len", C.c_uint32),
+                ("max_len", C.c_uint32)]
+
+
 SYMBOLS = [
     ("sa_last_error", C.c_char_p, []),
     ("sa_device_count", C.c_int, []),
@@ -75,6 +85,10 @@ SYMBOLS = [
       C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("sa_chain_batch_device", C.c_int,
      [C.c_int, C.c_void_p, C.POINTER(ChainBatch), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("sa_ingest_workspace_bytes", C.c_size_t, [C.c_uint64]),
+    ("sa_ingest_device", C.c_int, [C.c_int, C.c_void_p, C.POINTER(IngestBatch), C.c_void_p, C.c_size_t]),
+    ("sa_pack2bit_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("sa_unpack2bit_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("sa_remove_duplicate_host", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
 ]

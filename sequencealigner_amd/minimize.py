@@ -24,21 +24,38 @@ def _as_u8(x):
 class DeviceMinimizeBatch:
     def __init__(self, seqs, k, w, variant=capi.SA_MIN_BINARY, device=0, out_capacity=None):
         from . import synth
+        blob, off = synth.to_blob(seqs if isinstance(seqs, np.ndarray) and seqs.ndim == 2
+                                  else [_as_u8(s) for s in seqs])
+        lens = np.diff(off.astype(np.int64))
+        self.lens = lens
+        dev = torch.device("cuda", device)
+        # the kernels fetch bases with 8-byte loads: keep 8 bytes of slack behind the blob
+        d_seq = torch.from_numpy(np.concatenate([blob, np.zeros(16, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(off.astype(np.uint64).view(np.int64)).to(dev)
+        windows = int((lens - (int(k) + int(w) - 2)).clip(min=0).sum())
+        self._setup(d_seq, d_off, len(off) - 1, int(off[-1]), int(lens.min()), int(lens.max()), k, w, variant,
+                    device, out_capacity, windows)
+
+    @classmethod
+    def from_device(cls, d_seq, d_off, n, total_len, min_len, max_len, k, w, variant=capi.SA_MIN_BINARY,
+                    device=0, out_capacity=None):
+        """A batch over sequences that already lie in device memory (d_seq: uint8 blob with 8 bytes of slack
+        behind total_len, d_off: int64 [n + 1]), e.g. as ingest.DeviceRecords holds them."""
+        self = cls.__new__(cls)
+        self.lens = None
+        self._setup(d_seq, d_off, n, total_len, min_len, max_len, k, w, variant, device, out_capacity, None)
+        return self
+
+    def _setup(self, d_seq, d_off, n, total_len, min_len, max_len, k, w, variant, device, out_capacity, windows):
         self.lib = capi.lib()
         self.device = torch.device("cuda", device)
         self.dev_index = device
-        blob, off = synth.to_blob(seqs if isinstance(seqs, np.ndarray) and seqs.ndim == 2
-                                  else [_as_u8(s) for s in seqs])
-        self.n = len(off) - 1
-        lens = np.diff(off.astype(np.int64))
-        self.lens = lens
+        self.n = int(n)
         self.k, self.w, self.variant = int(k), int(w), int(variant)
-        self.total_len = int(off[-1])
-        self.max_len, self.min_len = int(lens.max()), int(lens.min())
-        self.windows = int((lens - (self.k + self.w - 2)).clip(min=0).sum())
-        # the kernels fetch bases with 8-byte loads: keep 8 bytes of slack behind the blob
-        self.d_seq = torch.from_numpy(np.concatenate([blob, np.zeros(16, np.uint8)])).to(self.device)
-        self.d_off = torch.from_numpy(off.astype(np.uint64).view(np.int64)).to(self.device)
+        self.total_len = int(total_len)
+        self.max_len, self.min_len = int(max_len), int(min_len)
+        self.windows = windows
+        self.d_seq, self.d_off = d_seq, d_off
         cap = self.lib.sa_minimize_out_capacity(self.n, self.total_len, self.k, self.w)
         self.out_capacity = int(out_capacity if out_capacity is not None else cap)
         self.d_out = torch.empty(max(self.out_capacity, 1) * 3, dtype=torch.int32, device=self.device)

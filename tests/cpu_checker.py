@@ -40,6 +40,10 @@ class CpuChecker:
             L.sa_cpu_chain_batch.restype = None
             L.sa_cpu_chain_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
                                              C.c_size_t, C.c_void_p, C.c_void_p]
+        if hasattr(L, "sa_cpu_parse"):
+            L.sa_cpu_parse.restype = C.c_int64
+            L.sa_cpu_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_uint64]
         L.sa_cpu_kind.restype = C.c_char_p
         self.kind = L.sa_cpu_kind().decode()
 
@@ -99,6 +103,23 @@ class CpuChecker:
         self.lib.sa_cpu_chain_batch(ref.ctypes.data, len(ref), f, rd.ctypes.data, off.ctypes.data, n,
                                     out.ctypes.data, nm.ctypes.data)
         return out, nm
+
+    def parse(self, data, fmt):
+        """File bytes -> (seq blob, seq_off, name_start, name_len, qual_start) as numpy arrays, or None for a
+        file that breaks the format (fmt 0 = FASTA, 1 = FASTQ)."""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        n = buf.size
+        cap = n // 2 + 2
+        seq = np.zeros(max(n, 1), dtype=np.uint8)
+        off = np.zeros(cap + 1, dtype=np.uint64)
+        ns = np.zeros(cap, dtype=np.uint64)
+        nl = np.zeros(cap, dtype=np.uint32)
+        qs = np.zeros(cap, dtype=np.uint64)
+        r = self.lib.sa_cpu_parse(buf.ctypes.data if n else None, n, fmt, seq.ctypes.data, off.ctypes.data,
+                                  ns.ctypes.data, nl.ctypes.data, qs.ctypes.data, cap)
+        if r < 0:
+            return None
+        return seq[:int(off[r])].copy(), off[:r + 1].copy(), ns[:r].copy(), nl[:r].copy(), qs[:r].copy()
 
     def cigar_block_match(self, cigar):
         """(alignment block length, match length) as the reference's mapper computes them from CIGAR text."""

@@ -80,3 +80,33 @@ def test_chain_restatement_hand_cases(oracle):
     # f = 0.4: (int)(3 * 0.4) = 1 value dropped: the one with the most occurrences (7)
     out, nm = oracle.chain_batch(ref, reads, off, 0.4)
     assert list(nm) == [2, 0, 0] and out[0].tolist() == [2, 100, 200, 30, 60]
+
+
+def test_sequence_file_rules_of_the_restatement(oracle):
+    """Hand cases for the FASTA / FASTQ rules the device parser is checked against (the parser behind the
+    reference's mapper is an un-vendored submodule: parity unpinned)."""
+    seq, off, ns, nl, qs = oracle.parse(b">r1 desc\nACGT\nAC\n>r2\nGG\r\nTT\n", 0)
+    assert bytes(seq) == b"ACGTACGGTT" and off.tolist() == [0, 6, 10]
+    assert ns.tolist() == [1, 18] and nl.tolist() == [2, 2]
+    # a '>' inside a header line is text; quality lines may start with '@' or '+'
+    seq, off, ns, nl, qs = oracle.parse(b">a>b x\nAC\n", 0)
+    assert bytes(seq) == b"AC" and nl.tolist() == [3]
+    seq, off, ns, nl, qs = oracle.parse(b"@q1 x\nACGT\n+\n@III\n@q2\nAC\n+q2\n+I", 1)
+    assert bytes(seq) == b"ACGTAC" and off.tolist() == [0, 4, 6] and qs.tolist() == [13, 29]
+    for bad, fmt in ((b"ACGT\n", 0), (b">\nAC\n", 0), (b">a\n", 0), (b"@a\nAC\n+\nI\n", 1), (b"@a\nAC\n+\n", 1)):
+        assert oracle.parse(bad, fmt) is None
+    assert oracle.parse(b"", 0)[1].tolist() == [0]
+
+
+def test_file_name_tests_split_and_stats():
+    from sequencealigner_amd import ingest
+    # the mapper tests ".fa" first, as a substring: a ".fastq" name is taken for FASTA (src/mapper.cpp:135-150)
+    assert ingest.format_of("ref.fasta") == ingest.FASTA and ingest.format_of("reads.fastq") == ingest.FASTA
+    assert ingest.format_of("reads.fq") == ingest.FASTQ and ingest.format_of("reads.sanfastq") == ingest.FASTQ
+    assert ingest.format_of("reads.txt") is None
+    short, long_ = ingest.split_fragments([10, 5000, 4999, 70000])
+    assert short.tolist() == [0, 2] and long_.tolist() == [1, 3]
+    st = ingest.stats([300, 100, 500, 200], ["a", "b", "c", "d"])
+    # N50 as the mapper computes it: file order, first fragment at which the running sum exceeds half
+    assert st == {"count": 4, "total": 1100, "longest": 500, "longest_name": "c", "shortest": 100,
+                  "shortest_name": "b", "average": 275.0, "n50": 500}
