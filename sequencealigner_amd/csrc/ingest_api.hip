@@ -10,7 +10,7 @@
 //   FASTQ  four lines per record: '@' header (name as above), bases, a line starting with '+', qualities
 //          (as many as bases).  Records whose bases or qualities are split over several lines are rejected.
 //
-// Structure: one wave per 16 KiB tile of the file.  The wave walks its tile 64 bytes at a time, one byte
+// Structure: one wave per tile of the file (16 KiB, less for small files).  The wave walks its tile 64 bytes at a time, one byte
 // per lane; __ballot turns "is '\n'", "is '>'", "is white space" into 64-bit lane masks that live in
 // scalar registers, and the header / line-phase state machine runs on those masks: for FASTA the
 // "inside a header" latch (set by '>', cleared by '\n') is the carry chain of one 64-bit addition.
@@ -30,8 +30,7 @@ namespace {
 
 constexpr uint32_t kWaves = 4;          // waves per block, one tile each
 constexpr uint32_t kSlab = 1024;        // bytes of the tile a wave holds in LDS at a time (16 per lane)
-constexpr uint32_t kSlabsPerTile = 16;
-constexpr uint64_t kTile = (uint64_t)kSlab * kSlabsPerTile;
+constexpr uint32_t kMaxSlabsPerTile = 16;  // tiles are 1 .. 16 slabs: small files still fill the GPU
 
 // error bits (device) -> messages (host)
 enum : uint32_t {
@@ -76,6 +75,7 @@ struct IngestArgs {
   const uint8_t* file;
   uint64_t n;
   uint64_t n_tiles;
+  uint32_t slabs;      // slabs per tile
   const TileSum* pre;  // inclusive scan of the tile summaries
   uint8_t* seq;
   uint64_t* seq_off;
@@ -93,10 +93,10 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Lane L brings bytes [base + 16 L, base + 16 L + 16) of the file into the wave's slab; bytes past the end
-// of the file read as blanks, which no rule below keeps or reacts to.
-__device__ __forceinline__ void load_slab(const uint8_t* file, uint64_t n, uint64_t base, uint32_t lane,
-                                          uint8_t* slab) {
+// Lane L fetches bytes [base + 16 L, base + 16 L + 16) of the file; bytes past the end of the file read as
+// blanks, which no rule below keeps or reacts to.  The fetch of the next slab is issued before the current
+// one is walked and lands in the wave's LDS slab afterwards (put_slab).
+__device__ __forceinline__ uint4 fetch_slab(const uint8_t* file, uint64_t n, uint64_t base, uint32_t lane) {
   const uint64_t at = base + 16ull * lane;
   uint4 v = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
   if (at + 16 <= n) {
@@ -108,6 +108,10 @@ __device__ __forceinline__ void load_slab(const uint8_t* file, uint64_t n, uint6
       if (at + j < n) w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)file[at + j] << (8 * (j & 3)));
     v = make_uint4(w[0], w[1], w[2], w[3]);
   }
+  return v;
+}
+
+__device__ __forceinline__ void put_slab(uint4 v, uint32_t lane, uint8_t* slab) {
   __builtin_amdgcn_wave_barrier();  // the previous slab has been read
   *reinterpret_cast<uint4*>(slab + 16 * lane) = v;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -122,6 +126,11 @@ __device__ __forceinline__ FastaMasks fasta_round(uint32_t b, uint32_t& inside) 
   FastaMasks m;
   const uint64_t gt = __ballot(b == '>'), ws = __ballot(is_space(b));
   m.nl = __ballot(b == '\n');
+  if (!(gt | m.nl)) {  // no event: all 64 bytes share the state
+    m.keep = inside ? 0 : ~ws;
+    m.starts = 0;
+    return m;
+  }
   // latch: after_i = gt_i | (~nl_i & after_{i-1}).  In the sum ~nl + gt + inside bit i generates a carry
   // where gt, propagates one where neither gt nor nl and kills it where nl, so the carry into bit i is
   // "inside a header before byte i".
@@ -134,19 +143,18 @@ __device__ __forceinline__ FastaMasks fasta_round(uint32_t b, uint32_t& inside) 
   return m;
 }
 
-// FASTQ, 64 bytes: phase[j] = the bytes on lines with index j mod 4, `line` = index of the line the first
-// byte is on, `at_line_start` = 1 if that byte begins its line.
+// FASTQ, 64 bytes with at least one line end or line start among them: phase[j] = the bytes on lines with
+// index j mod 4, `line` = index of the line the first byte is on, `at_line_start` = 1 if that byte begins
+// its line.  (Groups without either lie on one line and are handled by the callers directly.)
 struct FastqMasks {
-  uint64_t nl, ws, line_start, phase[4];
+  uint64_t line_start, phase[4];
 };
-__device__ __forceinline__ FastqMasks fastq_round(uint32_t b, uint64_t line, uint32_t& at_line_start) {
+__device__ __forceinline__ FastqMasks fastq_round(uint64_t nl, uint64_t line, uint32_t& at_line_start) {
   FastqMasks m;
-  m.nl = __ballot(b == '\n');
-  m.ws = __ballot(is_space(b));
-  m.line_start = (m.nl << 1) | at_line_start;
-  at_line_start = (uint32_t)(m.nl >> 63);
+  m.line_start = (nl << 1) | at_line_start;
+  at_line_start = (uint32_t)(nl >> 63);
   m.phase[0] = m.phase[1] = m.phase[2] = m.phase[3] = 0;
-  uint64_t rem = m.nl, from = ~0ull;  // `from`: the bytes at and after the current line's first byte
+  uint64_t rem = nl, from = ~0ull;  // `from`: the bytes at and after the current line's first byte
   uint32_t ph = (uint32_t)line & 3u;
   while (true) {
     const uint64_t upto = rem ? (((rem & (0 - rem)) << 1) - 1) : ~0ull;  // up to and including its '\n'
@@ -165,7 +173,7 @@ __device__ __forceinline__ FastqMasks fastq_round(uint32_t b, uint64_t line, uin
 
 template <int FORMAT>
 __global__ __launch_bounds__(kWaves * 64) void ingest_count(const uint8_t* file, uint64_t n, uint64_t n_tiles,
-                                                            TileSum* sums) {
+                                                            uint32_t slabs_per_tile, TileSum* sums) {
   __shared__ __align__(16) uint8_t slabs[kWaves][kSlab];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint64_t tile = (uint64_t)blockIdx.x * kWaves + wave;
@@ -174,13 +182,17 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_count(const uint8_t* file,
   TileSum t;
   t.c[0] = t.c[1] = t.c[2] = t.c[3] = 0;
   t.a = 0;
-  uint32_t inside = 0, at_line_start = 0;
+  uint32_t inside = 0;
   bool seen_nl = false;
   uint64_t pre_kept = 0, pre_starts = 0;  // FASTA: kept / started before the tile's first '\n'
-  for (uint32_t s = 0; s < kSlabsPerTile; ++s) {
-    const uint64_t base = tile * kTile + (uint64_t)s * kSlab;
+  uint64_t on_line = 0;                   // FASTQ: non-white-space bytes on the current line so far
+  uint4 next = fetch_slab(file, n, tile * slabs_per_tile * kSlab, lane);
+  for (uint32_t s = 0; s < slabs_per_tile; ++s) {
+    const uint64_t base = (tile * slabs_per_tile + s) * kSlab;
     if (base >= n) break;
-    load_slab(file, n, base, lane, slab);
+    put_slab(next, lane, slab);
+    if (s + 1 < slabs_per_tile) next = fetch_slab(file, n, base + kSlab, lane);
+#pragma unroll
     for (uint32_t r = 0; r < kSlab / 64; ++r) {
       const uint32_t b = slab[64 * r + lane];
       if (FORMAT == SA_FMT_FASTA) {
@@ -194,10 +206,24 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_count(const uint8_t* file,
           seen_nl = m.nl != 0;
         }
       } else {
-        const FastqMasks m = fastq_round(b, t.a, at_line_start);
+        const uint64_t nl = __ballot(b == '\n'), text = ~__ballot(is_space(b));
+        if (!nl) {
+          on_line += __popcll(text);
+        } else {  // close every line that ends here
+          uint64_t rem = nl, from = ~0ull;
+          while (rem) {
+            const uint64_t upto = ((rem & (0 - rem)) << 1) - 1;
+            on_line += __popcll(text & from & upto);
+            const uint32_t ph = (uint32_t)t.a & 3u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t.c[j] += __popcll(m.phase[j] & ~m.ws);
-        t.a += __popcll(m.nl);
+            for (uint32_t j = 0; j < 4; ++j) t.c[j] += ph == j ? on_line : 0;
+            on_line = 0;
+            t.a += 1;
+            rem &= rem - 1;
+            from = ~upto;
+          }
+          on_line = __popcll(text & from);
+        }
       }
     }
   }
@@ -206,8 +232,12 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_count(const uint8_t* file,
     t.c[1] = t.c[0] - pre_kept;
     t.c[3] = t.c[2] - pre_starts;
     t.a = inside | ((seen_nl ? inside : 1u) << 1);
-  } else if (tile == n_tiles - 1 && file[n - 1] != '\n') {
-    t.a += 1;  // the last line has no '\n': count it, so that the total is the number of lines
+  } else {
+    const uint32_t ph = (uint32_t)t.a & 3u;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) t.c[j] += ph == j ? on_line : 0;
+    if (tile == n_tiles - 1 && file[n - 1] != '\n')
+      t.a += 1;  // the last line has no '\n': count it, so that the total is the number of lines
   }
   if (lane == 0) sums[tile] = t;
 }
@@ -237,7 +267,7 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_write(IngestArgs a) {
   uint32_t inside = (uint32_t)pre.a & 1u;
   uint64_t line = pre.a;
   uint32_t at_line_start = 1;
-  if (FORMAT == SA_FMT_FASTQ && tile) at_line_start = a.file[tile * kTile - 1] == '\n';
+  if (FORMAT == SA_FMT_FASTQ && tile) at_line_start = a.file[tile * a.slabs * kSlab - 1] == '\n';
   uint64_t rec = FORMAT == SA_FMT_FASTA ? pre.c[2] : 0;
   const uint64_t first = FORMAT == SA_FMT_FASTA ? pre.c[0] : pre.c[1];  // blob offset of the tile's first kept byte
   if (tile == 0 && lane == 0) {
@@ -250,10 +280,13 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_write(IngestArgs a) {
   uint32_t head = (uint32_t)first & 15u, fill = head;
   uint64_t unit = first - head;
 
-  for (uint32_t s = 0; s < kSlabsPerTile; ++s) {
-    const uint64_t base = tile * kTile + (uint64_t)s * kSlab;
+  uint4 next = fetch_slab(a.file, a.n, tile * a.slabs * kSlab, lane);
+  for (uint32_t s = 0; s < a.slabs; ++s) {
+    const uint64_t base = (tile * a.slabs + s) * kSlab;
     if (base >= a.n) break;
-    load_slab(a.file, a.n, base, lane, slab);
+    put_slab(next, lane, slab);
+    if (s + 1 < a.slabs) next = fetch_slab(a.file, a.n, base + kSlab, lane);
+#pragma unroll
     for (uint32_t r = 0; r < kSlab / 64; ++r) {
       const uint32_t b = slab[64 * r + lane];
       const uint64_t pos = base + 64 * r + lane;
@@ -273,12 +306,15 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_write(IngestArgs a) {
           rec += __popcll(m.starts);
         }
       } else {
-        const FastqMasks m = fastq_round(b, line, at_line_start);
-        keep = m.phase[1] & ~m.ws;
-        const uint64_t events = m.line_start & ~m.phase[1] & __ballot(pos < a.n);
-        if (events) {
+        const uint64_t nl = __ballot(b == '\n');
+        if (!nl && !at_line_start) {  // one line, nothing starts: bases are kept, the rest is skipped
+          keep = (line & 3u) == 1 ? ~__ballot(is_space(b)) : 0;
+        } else {
+          const FastqMasks m = fastq_round(nl, line, at_line_start);
+          keep = m.phase[1] & ~__ballot(is_space(b));
+          const uint64_t events = m.line_start & ~m.phase[1] & __ballot(pos < a.n);
           if ((events >> lane) & 1u) {
-            const uint64_t my_line = line + lanes_below(m.nl);
+            const uint64_t my_line = line + lanes_below(nl);
             const uint64_t id = my_line >> 2;
             const uint32_t ph = (uint32_t)my_line & 3u;
             if (ph == 0) {
@@ -296,9 +332,10 @@ __global__ __launch_bounds__(kWaves * 64) void ingest_write(IngestArgs a) {
               a.qual_start[id] = pos;
             }
           }
+          line += __popcll(nl);
         }
-        line += __popcll(m.nl);
       }
+      if (!keep) continue;
       if ((keep >> lane) & 1u) out[fill + lanes_below(keep)] = (uint8_t)b;
       fill += __popcll(keep);
     }
@@ -419,11 +456,15 @@ __global__ void unpack2bit(const uint64_t* packed, const uint32_t* other, uint64
 
 struct IngestPlan {
   uint64_t n_tiles;
+  uint32_t slabs;
   size_t o_sums, o_pre, o_flags, o_tmp, scan_tmp, total;
 };
 
 int make_ingest_plan(uint64_t n_bytes, IngestPlan* pl) {
-  pl->n_tiles = (n_bytes + kTile - 1) / kTile;
+  // at least ~16 K tiles (waves) where the file allows it, tiles of at most 16 KiB
+  pl->slabs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_bytes / ((uint64_t)kSlab << 14), 1), kMaxSlabsPerTile);
+  const uint64_t tile_bytes = (uint64_t)pl->slabs * kSlab;
+  pl->n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
   const size_t tiles = (size_t)std::max<uint64_t>(pl->n_tiles, 1);
   size_t t1 = 0, t2 = 0;
   TileSum* p = nullptr;
@@ -445,9 +486,9 @@ int make_ingest_plan(uint64_t n_bytes, IngestPlan* pl) {
 }
 
 template <int FORMAT>
-void launch_count(hipStream_t stream, const uint8_t* file, uint64_t n, uint64_t n_tiles, TileSum* sums) {
-  hipLaunchKernelGGL(ingest_count<FORMAT>, dim3((unsigned)((n_tiles + kWaves - 1) / kWaves)), dim3(kWaves * 64), 0,
-                     stream, file, n, n_tiles, sums);
+void launch_count(hipStream_t stream, const uint8_t* file, uint64_t n, const IngestPlan& pl, TileSum* sums) {
+  hipLaunchKernelGGL(ingest_count<FORMAT>, dim3((unsigned)((pl.n_tiles + kWaves - 1) / kWaves)), dim3(kWaves * 64),
+                     0, stream, file, n, pl.n_tiles, pl.slabs, sums);
 }
 
 template <int FORMAT>
@@ -490,8 +531,8 @@ extern "C" int sa_ingest_device(int device, void* stream_, sa_ingest_batch* b, v
   uint32_t* flags = (uint32_t*)(ws + pl.o_flags);  // error bits, min length, max length
   const bool fasta = b->format == SA_FMT_FASTA;
 
-  if (fasta) launch_count<SA_FMT_FASTA>(stream, b->d_file, b->n_bytes, pl.n_tiles, sums);
-  else launch_count<SA_FMT_FASTQ>(stream, b->d_file, b->n_bytes, pl.n_tiles, sums);
+  if (fasta) launch_count<SA_FMT_FASTA>(stream, b->d_file, b->n_bytes, pl, sums);
+  else launch_count<SA_FMT_FASTQ>(stream, b->d_file, b->n_bytes, pl, sums);
   SA_HIP_TRY(hipGetLastError());
   size_t t = pl.scan_tmp;
   if (fasta) SA_HIP_TRY(rocprim::inclusive_scan(ws + pl.o_tmp, t, sums, pre, (size_t)pl.n_tiles, FastaJoin(), stream));
@@ -520,7 +561,7 @@ extern "C" int sa_ingest_device(int device, void* stream_, sa_ingest_batch* b, v
     return fail(SA_ERR_ARGUMENT, "NULL output pointer");
   if ((uintptr_t)b->d_seq & 15u) return fail(SA_ERR_ARGUMENT, "d_seq must be 16-byte aligned");
 
-  IngestArgs a{b->d_file, b->n_bytes, pl.n_tiles, pre, b->d_seq, b->d_seq_off, b->d_name_start, b->d_name_len,
+  IngestArgs a{b->d_file, b->n_bytes, pl.n_tiles, pl.slabs, pre, b->d_seq, b->d_seq_off, b->d_name_start, b->d_name_len,
                b->d_qual_start, b->n_records, b->n_bases, flags, flags + 1};
   if (fasta) launch_write<SA_FMT_FASTA>(stream, a);
   else launch_write<SA_FMT_FASTQ>(stream, a);

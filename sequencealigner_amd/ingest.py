@@ -36,7 +36,7 @@ class DeviceRecords:
         ws = torch.empty(lib.sa_ingest_workspace_bytes(n_bytes), dtype=torch.uint8, device=dev)
         b = capi.IngestBatch()
         b.d_file, b.n_bytes, b.format = d_file.data_ptr(), n_bytes, fmt
-        cap_rec, cap_seq = n_bytes // 256 + 16, 0  # first call sizes the blob; the record guess may grow
+        cap_rec, cap_seq = n_bytes // 256 + 16, n_bytes  # the file size bounds the blob; the record guess may grow
         for _ in range(3):
             self.d_seq = torch.empty(cap_seq + 16, dtype=torch.uint8, device=dev)
             self.d_seq_off = torch.zeros(cap_rec + 1, dtype=torch.int64, device=dev)
