@@ -274,6 +274,13 @@ int sa_pack2bit_device(int device, void* stream, const uint8_t* d_seq, uint64_t 
 int sa_unpack2bit_device(int device, void* stream, const uint64_t* d_packed, const uint32_t* d_other,
                          uint64_t n_bases, uint8_t* d_seq);
 
+/* Copies n spans of a device blob back to back: span i is d_src[d_src_start[i] .. + d_dst_off[i+1] - d_dst_off[i])
+ * and lands at d_dst + d_dst_off[i].  The device form of the substr() calls with which the mapper cuts the
+ * chained parts out of read and reference before Align (reference src/mapper.cpp:423-424), so that ingested
+ * records can be aligned without visiting the host. */
+int sa_gather_spans_device(int device, void* stream, const uint8_t* d_src, const uint64_t* d_src_start,
+                           const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst);
+
 /* removeDuplicate on the device (reference src/utility.cpp:8-26): sorts n triples in place by
  * (value, position, strand) and writes the distinct ones to out (capacity n); *out_n = their number. */
 int sa_remove_duplicate_host(uint32_t* triples, size_t n, uint32_t* out, size_t* out_n);

@@ -48,30 +48,46 @@ class DeviceAlignBatch:
     def __init__(self, queries, targets, type_, match, mismatch, gap, want_cigar=True,
                  want_target_begin=True, device=0, workspace_bytes=None):
         from . import synth
+        qb, qo = synth.to_blob(queries if isinstance(queries, np.ndarray) else [_as_u8(x) for x in queries])
+        tb, to = synth.to_blob(targets if isinstance(targets, np.ndarray) else [_as_u8(x) for x in targets])
+        assert len(to) == len(qo)
+        qlens = np.diff(qo.astype(np.int64))
+        tlens = np.diff(to.astype(np.int64))
+        ddev = torch.device("cuda", device)
+
+        def dev(a, dtype):
+            t = torch.from_numpy(np.ascontiguousarray(a).view(dtype) if a.size else np.zeros(1, dtype))
+            return t.to(ddev)
+
+        # +8 bytes of slack so that kernels may read whole dwords at the end of the blob
+        self._setup(dev(np.concatenate([qb, np.zeros(8, np.uint8)]), np.uint8),
+                    dev(qo.astype(np.uint64).view(np.int64), np.int64),
+                    dev(np.concatenate([tb, np.zeros(8, np.uint8)]), np.uint8),
+                    dev(to.astype(np.uint64).view(np.int64), np.int64), qlens, tlens, type_, match, mismatch, gap,
+                    want_cigar, want_target_begin, device, workspace_bytes)
+
+    @classmethod
+    def from_device(cls, d_q, d_qo, d_t, d_to, qlens, tlens, type_, match, mismatch, gap, want_cigar=True,
+                    want_target_begin=True, device=0, workspace_bytes=None):
+        """A batch over pairs that already lie in device memory: uint8 blobs with 8 bytes of slack, int64
+        offsets [n + 1]; qlens / tlens are the host copies of the lengths."""
+        self = cls.__new__(cls)
+        self._setup(d_q, d_qo, d_t, d_to, np.asarray(qlens, dtype=np.int64), np.asarray(tlens, dtype=np.int64),
+                    type_, match, mismatch, gap, want_cigar, want_target_begin, device, workspace_bytes)
+        return self
+
+    def _setup(self, d_q, d_qo, d_t, d_to, qlens, tlens, type_, match, mismatch, gap, want_cigar,
+               want_target_begin, device, workspace_bytes):
         self.lib = capi.lib()
         self.device = torch.device("cuda", device)
         self.dev_index = device
-        qb, qo = synth.to_blob(queries if isinstance(queries, np.ndarray) else [_as_u8(x) for x in queries])
-        tb, to = synth.to_blob(targets if isinstance(targets, np.ndarray) else [_as_u8(x) for x in targets])
-        self.n = len(qo) - 1
-        assert len(to) - 1 == self.n
-        qlens = np.diff(qo.astype(np.int64))
-        tlens = np.diff(to.astype(np.int64))
+        self.n = len(qlens)
         self.qlens, self.tlens = qlens, tlens
         self.max_q = int(qlens.max()) if self.n else 0
         self.max_t = int(tlens.max()) if self.n else 0
         self.cells = int((qlens * tlens).sum())
         self.type, self.match, self.mismatch, self.gap = int(type_), int(match), int(mismatch), int(gap)
-
-        def dev(a, dtype):
-            t = torch.from_numpy(np.ascontiguousarray(a).view(dtype) if a.size else np.zeros(1, dtype))
-            return t.to(self.device)
-
-        # +8 bytes of slack so that kernels may read whole dwords at the end of the blob
-        self.d_q = dev(np.concatenate([qb, np.zeros(8, np.uint8)]), np.uint8)
-        self.d_t = dev(np.concatenate([tb, np.zeros(8, np.uint8)]), np.uint8)
-        self.d_qo = dev(qo.astype(np.uint64).view(np.int64), np.int64)
-        self.d_to = dev(to.astype(np.uint64).view(np.int64), np.int64)
+        self.d_q, self.d_qo, self.d_t, self.d_to = d_q, d_qo, d_t, d_to
         n1 = max(self.n, 1)
         self.d_score = torch.zeros(n1, dtype=torch.int32, device=self.device)
         self.d_tb = torch.zeros(n1, dtype=torch.int32, device=self.device) if want_target_begin else None

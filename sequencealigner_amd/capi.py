@@ -89,6 +89,8 @@ SYMBOLS = [
     ("sa_ingest_device", C.c_int, [C.c_int, C.c_void_p, C.POINTER(IngestBatch), C.c_void_p, C.c_size_t]),
     ("sa_pack2bit_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("sa_unpack2bit_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("sa_gather_spans_device", C.c_int,
+     [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("sa_remove_duplicate_host", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
 ]

@@ -454,6 +454,16 @@ __global__ void unpack2bit(const uint64_t* packed, const uint32_t* other, uint64
   }
 }
 
+// dst[dst_off[i] + j] = src[src_start[i] + j] for j < dst_off[i + 1] - dst_off[i]; one wave per span.
+__global__ __launch_bounds__(256) void gather_spans(const uint8_t* src, const uint64_t* src_start,
+                                                    const uint64_t* dst_off, uint32_t n, uint8_t* dst) {
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (i >= n) return;
+  const uint64_t to = dst_off[i], len = dst_off[i + 1] - to;
+  const uint8_t* from = src + src_start[i];
+  for (uint64_t j = lane; j < len; j += 64) dst[to + j] = from[j];
+}
+
 struct IngestPlan {
   uint64_t n_tiles;
   uint32_t slabs;
@@ -606,6 +616,17 @@ extern "C" int sa_unpack2bit_device(int device, void* stream_, const uint64_t* d
   const uint64_t words = (n_bases + 31) / 32;
   hipLaunchKernelGGL(unpack2bit, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                      d_packed, d_other, n_bases, d_seq);
+  SA_HIP_TRY(hipGetLastError());
+  return SA_OK;
+}
+
+extern "C" int sa_gather_spans_device(int device, void* stream_, const uint8_t* d_src, const uint64_t* d_src_start,
+                                      const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst) {
+  if (n == 0) return SA_OK;
+  if (!d_src || !d_src_start || !d_dst_off || !d_dst) return fail(SA_ERR_ARGUMENT, "NULL pointer");
+  SA_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(gather_spans, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream_, d_src, d_src_start,
+                     d_dst_off, n, d_dst);
   SA_HIP_TRY(hipGetLastError());
   return SA_OK;
 }

@@ -131,3 +131,19 @@ def unpack2bit(d_packed, d_other, n_bases, device=0):
     capi.check(capi.lib().sa_unpack2bit_device(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream,
                                                d_packed.data_ptr(), d_other.data_ptr(), n_bases, seq.data_ptr()))
     return seq[:n_bases]
+
+
+def gather_spans(d_src, starts, lengths, device=0):
+    """Cuts spans out of a device blob: -> (uint8 blob of the spans back to back with 8 bytes of slack,
+    int64 offsets [n + 1]), both on the device.  starts / lengths are host arrays."""
+    dev = torch.device("cuda", device)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    off = np.zeros(len(lengths) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=off[1:])
+    d_off = torch.from_numpy(off).to(dev)
+    d_start = torch.from_numpy(np.asarray(starts, dtype=np.int64)).to(dev)
+    d_dst = torch.zeros(int(off[-1]) + 16, dtype=torch.uint8, device=dev)
+    capi.check(capi.lib().sa_gather_spans_device(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream,
+                                                 d_src.data_ptr(), d_start.data_ptr(), d_off.data_ptr(),
+                                                 len(lengths), d_dst.data_ptr()))
+    return d_dst, d_off

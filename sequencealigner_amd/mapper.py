@@ -8,7 +8,7 @@ the larger of the two spans; a read without a chain gets the "-1" record when CI
 import numpy as np
 import torch
 
-from . import align, chain, minimize, paf
+from . import align, chain, ingest, minimize, paf
 
 
 def _device_lists(seqs, k, w, device):
@@ -54,3 +54,74 @@ def map_reads(ref_name, ref_seq, read_names, reads, k=15, w=5, f=0.001, match=1,
         else:
             out.append(paf.paf_line(read_names[i], lens[i], -1, -1, ref_name, len(ref_seq), -1, -1, 0, 0))
     return out
+
+
+def _records_lists(rec, k, w, device):
+    b = minimize.DeviceMinimizeBatch.from_device(rec.d_seq, rec.d_seq_off, rec.n, rec.n_bases, rec.min_len,
+                                                 rec.max_len, k, w, device=device)
+    b.run()
+    torch.cuda.synchronize(device)
+    off = b.d_out_off.clone()
+    n = int(off[-1].item())
+    return b.d_out[:3 * n].clone().reshape(n, 3), off
+
+
+def map_records(ref, ref_name, reads, read_names, k=15, w=5, f=0.001, match=1, mismatch=-1, gap=-1,
+                cigar_needed=True, device=0):
+    """map_reads over ingested files (ingest.DeviceRecords): the bases stay on the device from the file copy
+    to the CIGAR runs.  `ref`'s first record is the reference, as the mapper uses s1[0]
+    (reference src/mapper.cpp:424, :636).  Records come out in the mapper's submission order: fragments of
+    5 000 bases and more first, then the shorter ones, each group in file order (:564-577, :665-675)."""
+    ref_off = ref.d_seq_off[:2].cpu().numpy()
+    ref_len = int(ref_off[1] - ref_off[0])
+    first = ingest.DeviceRecords.__new__(ingest.DeviceRecords)   # view of record 0
+    first.d_seq, first.d_seq_off, first.n, first.n_bases = ref.d_seq, ref.d_seq_off[:2], 1, ref_len
+    first.min_len = first.max_len = ref_len
+    d_ref, _ = _records_lists(first, k, w, device)
+    d_reads, d_off = _records_lists(reads, k, w, device)
+    spans = chain.chain_batch(d_ref, d_reads, d_off, f, device=device)
+    lens = reads.lengths()
+    read_off = reads.d_seq_off.cpu().numpy()
+    lis, tb, te, qb, qe = (spans[:, c].astype(np.int64) for c in range(5))
+    to_align = (lis > 0) & ((te - tb) < 100000) & cigar_needed & (lens < 5000)
+    idx = np.nonzero(to_align)[0]
+    cigars, block = {}, {}
+    if idx.size:
+        d_q, d_qo = ingest.gather_spans(reads.d_seq, read_off[idx] + qb[idx], qe[idx] - qb[idx], device)
+        d_t, d_to = ingest.gather_spans(ref.d_seq, tb[idx], te[idx] - tb[idx], device)
+        batch = align.DeviceAlignBatch.from_device(d_q, d_qo, d_t, d_to, qe[idx] - qb[idx], te[idx] - tb[idx],
+                                                   align.AlignmentType.Global, match, mismatch, gap, device=device)
+        batch.run()
+        torch.cuda.synchronize(device)
+        bl, _ = batch.cigar_stats()
+        for j, (i, c) in enumerate(zip(idx, batch.cigars())):
+            cigars[i], block[i] = c, int(bl[j])
+    short, long_ = ingest.split_fragments(lens)
+    out = []
+    for i in list(long_) + list(short):
+        if to_align[i]:
+            out.append(paf.paf_line(read_names[i], lens[i], qb[i], qe[i], ref_name, ref_len, tb[i], te[i], 0,
+                                    block[i], cigars[i]))
+        elif (not cigar_needed) or (te[i] - tb[i]) >= 100000 or lens[i] >= 5000:
+            out.append(paf.paf_line(read_names[i], lens[i], qb[i], qe[i], ref_name, ref_len, tb[i], te[i],
+                                    int(lis[i]) * k, max(int(qe[i] - qb[i]), int(te[i] - tb[i]))))
+        else:
+            out.append(paf.paf_line(read_names[i], lens[i], -1, -1, ref_name, ref_len, -1, -1, 0, 0))
+    return out
+
+
+def map_files(ref_path, reads_path, **kw):
+    """The mapper's main path from two file names (reference src/mapper.cpp:532-679): reference FASTA, reads
+    FASTA or FASTQ by the mapper's file-name tests; returns the PAF records."""
+    device = kw.get("device", 0)
+    ref_bytes = np.fromfile(ref_path, dtype=np.uint8)
+    read_bytes = np.fromfile(reads_path, dtype=np.uint8)
+    fmt = ingest.format_of(reads_path)
+    if fmt is None:
+        raise ValueError(f"{reads_path}: neither a FASTA nor a FASTQ file name")
+    dev = torch.device("cuda", device)
+    ref = ingest.DeviceRecords(torch.from_numpy(ref_bytes).to(dev), ingest.FASTA, device)
+    reads = ingest.DeviceRecords(torch.from_numpy(read_bytes).to(dev), fmt, device)
+    ref_name = ref.names(ref_bytes.tobytes())[0].decode()
+    read_names = [x.decode() for x in reads.names(read_bytes.tobytes())]
+    return map_records(ref, ref_name, reads, read_names, **kw)

@@ -53,3 +53,35 @@ def test_pipeline_records_vs_cpu_composition(oracle, cigar_needed):
     assert len(got) == len(want)
     same = sum(g == w for g, w in zip(got, want))
     assert got == want, (same, len(want))
+
+
+def test_files_to_paf_records_on_the_device(tmp_path):
+    """FASTA + FASTQ files -> ingest -> minimizers -> chaining -> alignment -> PAF, bases never on the host
+    in between; the records must equal those of map_reads on the same sequences, in the mapper's order
+    (fragments of 5 000 bases and more first)."""
+    from sequencealigner_amd import mapper, synth
+    rng = random.Random(5)
+    ref = bytes(synth.genome(90_000, seed=81))
+    reads, names = [], []
+    for i in range(120):
+        L = rng.choice([150, 700, 3000, 4999, 5000, 7000])
+        p = rng.randint(0, len(ref) - L)
+        s = bytearray(ref[p:p + L])
+        for x in range(len(s)):
+            if rng.random() < 0.03:
+                s[x] = rng.choice(b"ACGT")
+        reads.append(bytes(s))
+        names.append("read%d" % i)
+    fa = tmp_path / "ref.fasta"
+    with open(fa, "wb") as fh:
+        fh.write(b">chrT synthetic\n")
+        for j in range(0, len(ref), 70):
+            fh.write(ref[j:j + 70] + b"\n")
+    fq = tmp_path / "reads.fq"
+    with open(fq, "wb") as fh:
+        for n, r in zip(names, reads):
+            fh.write(b"@" + n.encode() + b" x\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    got = mapper.map_files(str(fa), str(fq), k=15, w=5, f=0.001, match=1, mismatch=-1, gap=-1, cigar_needed=True)
+    order = [i for i in range(len(reads)) if len(reads[i]) >= 5000] + [i for i in range(len(reads)) if len(reads[i]) < 5000]
+    want = mapper.map_reads("chrT", ref, names, reads, 15, 5, 0.001, 1, -1, -1, True)
+    assert got == [want[i] for i in order]
