@@ -106,6 +106,9 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        # torch ships its own HIP runtime; loading it first makes the process use one runtime whichever
+        # of the two libraries is touched first (two runtimes in one process do not see each other's GPU)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -130,8 +130,8 @@ Plan make_plan(const sa_align_batch& b) {
   } else if (max_q > 2048 || max_t > 2048) {
     want_wave = true;
   } else {
-    const double waves_lane = std::ceil(b.n / (pk16_ok ? 128.0 : 64.0));
-    const double lane_rate = std::min(waves_lane / 1024.0, 1.0) * (pk16_ok ? 5.3 : 0.9);
+    // a lane kernel's wavefront delivers its rate only with all of its 128 / 64 lanes' pairs present
+    const double lane_rate = std::min(b.n / (1024.0 * (pk16_ok ? 128.0 : 64.0)), 1.0) * (pk16_ok ? 5.3 : 0.9);
     const double strip_eff = max_q / (std::ceil(max_q / 1024.0) * 1024.0) * max_t / (max_t + 63.0);
     uint32_t unused_bias = 0;
     const bool wpk = !force_i32 && wave_pk16_applicable(b, &unused_bias);

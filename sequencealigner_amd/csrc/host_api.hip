@@ -3,14 +3,21 @@
 // the GPUs of the node by cost with no inter-GPU communication; one host thread per GPU stages its shard
 // through pinned memory, runs the device-resident batch call on its own stream and scatters the results
 // back to the caller's arrays in input order.
+//
+// Streams and buffers are kept between calls (HostContext): a call of one pair - what the C++ drop-in makes
+// of every Align() - costs copies, launches and one synchronisation, not a dozen allocations.  Large shards
+// are staged and their CIGAR text is formatted by several host threads.
 #include "sa_internal.h"
 
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -18,16 +25,27 @@
 namespace sa {
 namespace {
 
-struct DevBuf {
+// A buffer that only grows; device or pinned host memory.
+struct Buf {
   void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  int alloc(size_t bytes) {
-    if (p) (void)hipFree(p);
+  size_t cap = 0;
+  bool pinned = false;
+  void drop() {
+    if (p) (void)(pinned ? hipHostFree(p) : hipFree(p));
     p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
-    if (e != hipSuccess) return fail(SA_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    cap = 0;
+  }
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return SA_OK;
+    drop();
+    const size_t want = round_up(std::max(bytes, (size_t)4096), 4096);
+    const hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(SA_ERR_HIP, "%s(%zu) failed: %s", pinned ? "hipHostMalloc" : "hipMalloc", want,
+                  hipGetErrorString(e));
+    }
+    cap = want;
     return SA_OK;
   }
   template <class T>
@@ -36,29 +54,92 @@ struct DevBuf {
   }
 };
 
-struct PinBuf {
-  void* p = nullptr;
-  ~PinBuf() {
-    if (p) (void)hipHostFree(p);
-  }
-  int alloc(size_t bytes) {
-    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault);
-    if (e != hipSuccess)
-      return fail(SA_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    return SA_OK;
-  }
-  template <class T>
-  T* as() const {
-    return (T*)p;
+// One stream and one set of buffers on one GPU, used by one call at a time and kept for the next call.
+// Buffers above kKeepBytes are given back when the call ends, so that a single large batch does not pin
+// memory for the rest of the process.
+constexpr size_t kKeepBytes = (size_t)256 << 20;
+constexpr int kBufs = 12;
+struct HostContext {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Buf pin[kBufs], dev[kBufs];
+  HostContext() {
+    for (auto& b : pin) b.pinned = true;
   }
 };
 
-struct Stream {
-  hipStream_t s = nullptr;
-  ~Stream() {
-    if (s) (void)hipStreamDestroy(s);
+class ContextPool {
+ public:
+  HostContext* acquire(int device) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i]->device == device) {
+          HostContext* c = free_[i];
+          free_.erase(free_.begin() + i);
+          return c;
+        }
+    }
+    HostContext* c = new HostContext();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return nullptr;
+    }
+    return c;
+  }
+  void release(HostContext* c) {
+    for (auto& b : c->pin)
+      if (b.cap > kKeepBytes) b.drop();
+    for (auto& b : c->dev)
+      if (b.cap > kKeepBytes) b.drop();
+    std::lock_guard<std::mutex> g(m_);
+    free_.push_back(c);
+  }
+
+ private:
+  std::mutex m_;
+  std::vector<HostContext*> free_;  // never destroyed: the HIP runtime may be gone before static destructors run
+};
+
+ContextPool& pool() {
+  static ContextPool* p = new ContextPool();
+  return *p;
+}
+
+struct Lease {
+  HostContext* c;
+  explicit Lease(int device) : c(pool().acquire(device)) {}
+  ~Lease() {
+    if (c) pool().release(c);
   }
 };
+
+// Host threads a call may use for staging and text: SA_HOST_THREADS, else OMP_NUM_THREADS, else up to 16.
+unsigned host_threads() {
+  static const unsigned n = [] {
+    const char* e = getenv("SA_HOST_THREADS");
+    if (!e) e = getenv("OMP_NUM_THREADS");
+    unsigned v = e ? (unsigned)atoi(e) : 0;
+    if (!v) v = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::min(v, 64u);
+  }();
+  return n;
+}
+
+// f(begin, end) over [0, n) on up to `threads` host threads, at least `grain` items each.
+template <class F>
+void parallel_for(size_t n, size_t grain, unsigned threads, F f) {
+  const size_t parts = std::min<size_t>(std::max<size_t>(threads, 1), std::max<size_t>(n / grain, 1));
+  if (parts <= 1) {
+    f((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < parts; ++t) th.emplace_back([=]() { f(n * t / parts, n * (t + 1) / parts); });
+  f((size_t)0, n / parts);
+  for (auto& t : th) t.join();
+}
 
 int pick_devices(int requested) {
   int count = 0;
@@ -81,31 +162,49 @@ const char kOps[4] = {'M', 'X', 'I', 'D'};
 
 // "<count><op>..." exactly as CompressCigar prints it (src/alignment.cpp:17-33)
 char* runs_to_text(const uint32_t* runs, uint32_t n) {
-  std::string s;
-  s.reserve((size_t)n * 4 + 1);
+  char* out = (char*)malloc((size_t)n * 11 + 1);  // a run is at most 10 digits and a letter
+  if (!out) return nullptr;
+  char* w = out;
   for (uint32_t i = 0; i < n; ++i) {
-    s += std::to_string(runs[i] >> 2);
-    s += kOps[runs[i] & 3];
+    uint32_t v = runs[i] >> 2;
+    char digits[10];
+    int d = 0;
+    do {
+      digits[d++] = (char)('0' + v % 10);
+      v /= 10;
+    } while (v);
+    while (d) *w++ = digits[--d];
+    *w++ = kOps[runs[i] & 3];
   }
-  char* out = (char*)malloc(s.size() + 1);
-  if (out) memcpy(out, s.c_str(), s.size() + 1);
+  *w = 0;
   return out;
 }
 
-// One GPU's share of an alignment batch.
+// One GPU's share of an alignment batch; `threads` host threads may help with staging and text.
 int align_shard(int device, const std::vector<uint32_t>& idx, const char* const* queries,
                 const uint32_t* qlens, const char* const* targets, const uint32_t* tlens, int type,
                 int match, int mismatch, int gap, int32_t* scores, uint32_t* target_begin,
-                char** cigars) {
+                char** cigars, unsigned threads) {
   const uint32_t n = (uint32_t)idx.size();
   if (!n) return SA_OK;
   SA_HIP_TRY(hipSetDevice(device));
-  Stream st;
-  SA_HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+  Lease lease(device);
+  if (!lease.c) return fail(SA_ERR_HIP, "cannot create a stream on GPU %d", device);
+  HostContext& c = *lease.c;
+  hipStream_t st = c.stream;
+  enum { Q, T, QO, TO, SCORE, TB, NRUNS, RUNS, OFF, WS, COMPACT };
 
+  // pinned staging: offsets first, then the sequences (8 bytes of slack: the kernels read aligned 8-byte words)
+  int rc;
+  if ((rc = c.pin[QO].ensure((n + 1) * 8)) || (rc = c.pin[TO].ensure((n + 1) * 8))) return rc;
+  uint64_t* hqo = c.pin[QO].as<uint64_t>();
+  uint64_t* hto = c.pin[TO].as<uint64_t>();
   uint64_t qtot = 0, ttot = 0;
   uint32_t maxq = 0, maxt = 0, minq = ~0u, mint = ~0u;
-  for (uint32_t i : idx) {
+  for (uint32_t j = 0; j < n; ++j) {
+    const uint32_t i = idx[j];
+    hqo[j] = qtot;
+    hto[j] = ttot;
     qtot += qlens[i];
     ttot += tlens[i];
     maxq = std::max(maxq, qlens[i]);
@@ -113,44 +212,37 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
     minq = std::min(minq, qlens[i]);
     mint = std::min(mint, tlens[i]);
   }
-  // pinned staging: sequences + offsets (8 bytes of slack: the kernels read aligned 8-byte words)
-  PinBuf hq, ht, hqo, hto;
-  int rc;
-  if ((rc = hq.alloc(qtot + 16)) || (rc = ht.alloc(ttot + 16)) || (rc = hqo.alloc((n + 1) * 8)) ||
-      (rc = hto.alloc((n + 1) * 8)))
-    return rc;
-  uint64_t qo = 0, to = 0;
-  for (uint32_t j = 0; j < n; ++j) {
-    const uint32_t i = idx[j];
-    hqo.as<uint64_t>()[j] = qo;
-    hto.as<uint64_t>()[j] = to;
-    memcpy(hq.as<char>() + qo, queries[i], qlens[i]);
-    memcpy(ht.as<char>() + to, targets[i], tlens[i]);
-    qo += qlens[i];
-    to += tlens[i];
-  }
-  hqo.as<uint64_t>()[n] = qo;
-  hto.as<uint64_t>()[n] = to;
-  memset(hq.as<char>() + qo, 0, 16);
-  memset(ht.as<char>() + to, 0, 16);
+  hqo[n] = qtot;
+  hto[n] = ttot;
+  if ((rc = c.pin[Q].ensure(qtot + 16)) || (rc = c.pin[T].ensure(ttot + 16))) return rc;
+  char* hq = c.pin[Q].as<char>();
+  char* ht = c.pin[T].as<char>();
+  parallel_for(n, 8192, threads, [&](size_t b, size_t e) {
+    for (size_t j = b; j < e; ++j) {
+      const uint32_t i = idx[j];
+      memcpy(hq + hqo[j], queries[i], qlens[i]);
+      memcpy(ht + hto[j], targets[i], tlens[i]);
+    }
+  });
+  memset(hq + qtot, 0, 16);
+  memset(ht + ttot, 0, 16);
 
-  DevBuf dq, dt, dqo, dto, dscore, dtb, druns, dnruns, dws;
-  if ((rc = dq.alloc(qtot + 16)) || (rc = dt.alloc(ttot + 16)) || (rc = dqo.alloc((n + 1) * 8)) ||
-      (rc = dto.alloc((n + 1) * 8)) || (rc = dscore.alloc(n * 4)) || (rc = dtb.alloc(n * 4)))
-    return rc;
   const uint64_t stride = (uint64_t)maxq + maxt;
   const bool want_cigar = cigars != nullptr;
-  if (want_cigar && ((rc = druns.alloc((size_t)n * stride * 4)) || (rc = dnruns.alloc(n * 4)))) return rc;
-  SA_HIP_TRY(hipMemcpyAsync(dq.p, hq.p, qtot + 16, hipMemcpyHostToDevice, st.s));
-  SA_HIP_TRY(hipMemcpyAsync(dt.p, ht.p, ttot + 16, hipMemcpyHostToDevice, st.s));
-  SA_HIP_TRY(hipMemcpyAsync(dqo.p, hqo.p, (n + 1) * 8, hipMemcpyHostToDevice, st.s));
-  SA_HIP_TRY(hipMemcpyAsync(dto.p, hto.p, (n + 1) * 8, hipMemcpyHostToDevice, st.s));
+  if ((rc = c.dev[Q].ensure(qtot + 16)) || (rc = c.dev[T].ensure(ttot + 16)) || (rc = c.dev[QO].ensure((n + 1) * 8)) ||
+      (rc = c.dev[TO].ensure((n + 1) * 8)) || (rc = c.dev[SCORE].ensure(n * 4)) || (rc = c.dev[TB].ensure(n * 4)))
+    return rc;
+  if (want_cigar && ((rc = c.dev[RUNS].ensure((size_t)n * stride * 4)) || (rc = c.dev[NRUNS].ensure(n * 4)))) return rc;
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[Q].p, hq, qtot + 16, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[T].p, ht, ttot + 16, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[QO].p, hqo, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[TO].p, hto, (n + 1) * 8, hipMemcpyHostToDevice, st));
 
   sa_align_batch b{};
-  b.d_q = dq.as<uint8_t>();
-  b.d_q_off = dqo.as<uint64_t>();
-  b.d_t = dt.as<uint8_t>();
-  b.d_t_off = dto.as<uint64_t>();
+  b.d_q = c.dev[Q].as<uint8_t>();
+  b.d_q_off = c.dev[QO].as<uint64_t>();
+  b.d_t = c.dev[T].as<uint8_t>();
+  b.d_t_off = c.dev[TO].as<uint64_t>();
   b.n = n;
   b.max_qlen = maxq;
   b.max_tlen = maxt;
@@ -160,93 +252,104 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   b.match = match;
   b.mismatch = mismatch;
   b.gap = gap;
-  b.d_score = dscore.as<int32_t>();
-  b.d_target_begin = (target_begin || want_cigar) ? dtb.as<uint32_t>() : nullptr;
-  b.d_cigar_runs = want_cigar ? druns.as<uint32_t>() : nullptr;
-  b.d_cigar_nruns = want_cigar ? dnruns.as<uint32_t>() : nullptr;
+  b.d_score = c.dev[SCORE].as<int32_t>();
+  b.d_target_begin = (target_begin || want_cigar) ? c.dev[TB].as<uint32_t>() : nullptr;
+  b.d_cigar_runs = want_cigar ? c.dev[RUNS].as<uint32_t>() : nullptr;
+  b.d_cigar_nruns = want_cigar ? c.dev[NRUNS].as<uint32_t>() : nullptr;
   b.cigar_stride = stride;
 
   size_t min_ws = 0;
   size_t ws = sa_align_workspace_bytes(&b, &min_ws);
-  size_t free_b = 0, total_b = 0;
-  SA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  const size_t budget = (size_t)(free_b * 0.8);
-  if (ws > budget) ws = std::max(min_ws, budget / min_ws * min_ws);
-  if ((rc = dws.alloc(ws))) return rc;
-  if ((rc = sa_align_batch_device(device, st.s, &b, dws.p, ws))) return rc;
-
-  std::vector<int32_t> hscore(n);
-  std::vector<uint32_t> htb(n), hnr;
-  SA_HIP_TRY(hipMemcpyAsync(hscore.data(), dscore.p, n * 4, hipMemcpyDeviceToHost, st.s));
-  if (b.d_target_begin)
-    SA_HIP_TRY(hipMemcpyAsync(htb.data(), dtb.p, n * 4, hipMemcpyDeviceToHost, st.s));
-  if (want_cigar) {
-    hnr.resize(n);
-    SA_HIP_TRY(hipMemcpyAsync(hnr.data(), dnruns.p, n * 4, hipMemcpyDeviceToHost, st.s));
+  if (ws > c.dev[WS].cap) {  // a workspace kept from an earlier call serves as long as it holds one pass
+    size_t free_b = 0, total_b = 0;
+    SA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = (size_t)((free_b + c.dev[WS].cap) * 0.8);
+    if (ws > budget) ws = std::max(min_ws, budget / min_ws * min_ws);
+    if ((rc = c.dev[WS].ensure(ws))) return rc;
   }
-  SA_HIP_TRY(hipStreamSynchronize(st.s));
+  if ((rc = sa_align_batch_device(device, st, &b, c.dev[WS].p, c.dev[WS].cap))) return rc;
+
+  if ((rc = c.pin[SCORE].ensure(n * 4)) || (rc = c.pin[TB].ensure(n * 4)) || (rc = c.pin[NRUNS].ensure(n * 4)))
+    return rc;
+  const int32_t* hscore = c.pin[SCORE].as<int32_t>();
+  const uint32_t* htb = c.pin[TB].as<uint32_t>();
+  const uint32_t* hnr = c.pin[NRUNS].as<uint32_t>();
+  SA_HIP_TRY(hipMemcpyAsync(c.pin[SCORE].p, c.dev[SCORE].p, n * 4, hipMemcpyDeviceToHost, st));
+  if (b.d_target_begin) SA_HIP_TRY(hipMemcpyAsync(c.pin[TB].p, c.dev[TB].p, n * 4, hipMemcpyDeviceToHost, st));
+  if (want_cigar) SA_HIP_TRY(hipMemcpyAsync(c.pin[NRUNS].p, c.dev[NRUNS].p, n * 4, hipMemcpyDeviceToHost, st));
+  SA_HIP_TRY(hipStreamSynchronize(st));
   for (uint32_t j = 0; j < n; ++j) {
     scores[idx[j]] = hscore[j];
     if (target_begin) target_begin[idx[j]] = htb[j];
   }
   if (want_cigar) {
     // compact the runs on the device, then one copy back
-    std::vector<uint64_t> off(n + 1, 0);
+    if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
+    uint64_t* off = c.pin[OFF].as<uint64_t>();
+    off[0] = 0;
     for (uint32_t j = 0; j < n; ++j) off[j + 1] = off[j] + hnr[j];
-    DevBuf doff, dcompact;
-    if ((rc = doff.alloc((n + 1) * 8)) || (rc = dcompact.alloc(off[n] * 4))) return rc;
-    SA_HIP_TRY(hipMemcpyAsync(doff.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st.s));
-    hipLaunchKernelGGL(gather_runs, dim3(n), dim3(64), 0, st.s, druns.as<uint32_t>(),
-                       dnruns.as<uint32_t>(), doff.as<uint64_t>(), stride, n, dcompact.as<uint32_t>());
+    if ((rc = c.dev[OFF].ensure((n + 1) * 8)) || (rc = c.dev[COMPACT].ensure(off[n] * 4)) ||
+        (rc = c.pin[RUNS].ensure(off[n] * 4)))
+      return rc;
+    SA_HIP_TRY(hipMemcpyAsync(c.dev[OFF].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_runs, dim3(n), dim3(64), 0, st, c.dev[RUNS].as<uint32_t>(),
+                       c.dev[NRUNS].as<uint32_t>(), c.dev[OFF].as<uint64_t>(), stride, n,
+                       c.dev[COMPACT].as<uint32_t>());
     SA_HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> runs(off[n] ? off[n] : 1);
-    SA_HIP_TRY(hipMemcpyAsync(runs.data(), dcompact.p, off[n] * 4, hipMemcpyDeviceToHost, st.s));
-    SA_HIP_TRY(hipStreamSynchronize(st.s));
-    for (uint32_t j = 0; j < n; ++j) {
-      cigars[idx[j]] = runs_to_text(runs.data() + off[j], hnr[j]);
-      if (!cigars[idx[j]]) return fail(SA_ERR_ARGUMENT, "out of host memory");
-    }
+    SA_HIP_TRY(hipMemcpyAsync(c.pin[RUNS].p, c.dev[COMPACT].p, off[n] * 4, hipMemcpyDeviceToHost, st));
+    SA_HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t* runs = c.pin[RUNS].as<uint32_t>();
+    std::atomic<bool> oom{false};
+    parallel_for(n, 4096, threads, [&](size_t b0, size_t e0) {
+      for (size_t j = b0; j < e0; ++j) {
+        cigars[idx[j]] = runs_to_text(runs + off[j], hnr[j]);
+        if (!cigars[idx[j]]) oom = true;
+      }
+    });
+    if (oom) return fail(SA_ERR_ARGUMENT, "out of host memory");
   }
   return SA_OK;
 }
 
 int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* const* seqs,
                    const uint32_t* lens, uint32_t k, uint32_t w, int variant, uint32_t** out_triples,
-                   uint64_t* out_counts) {
+                   uint64_t* out_counts, unsigned threads) {
   const uint32_t n = (uint32_t)idx.size();
   if (!n) return SA_OK;
   SA_HIP_TRY(hipSetDevice(device));
-  Stream st;
-  SA_HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+  Lease lease(device);
+  if (!lease.c) return fail(SA_ERR_HIP, "cannot create a stream on GPU %d", device);
+  HostContext& c = *lease.c;
+  hipStream_t st = c.stream;
+  enum { SEQ, OFF, OUT, OOFF, STATUS, WS };
+  int rc;
+  if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
+  uint64_t* ho = c.pin[OFF].as<uint64_t>();
   uint64_t tot = 0;
   uint32_t maxl = 0, minl = ~0u;
-  for (uint32_t i : idx) {
-    tot += lens[i];
-    maxl = std::max(maxl, lens[i]);
-    minl = std::min(minl, lens[i]);
-  }
-  PinBuf hs, ho;
-  int rc;
-  if ((rc = hs.alloc(tot + 16)) || (rc = ho.alloc((n + 1) * 8))) return rc;
-  uint64_t o = 0;
   for (uint32_t j = 0; j < n; ++j) {
-    ho.as<uint64_t>()[j] = o;
-    memcpy(hs.as<char>() + o, seqs[idx[j]], lens[idx[j]]);
-    o += lens[idx[j]];
+    ho[j] = tot;
+    tot += lens[idx[j]];
+    maxl = std::max(maxl, lens[idx[j]]);
+    minl = std::min(minl, lens[idx[j]]);
   }
-  ho.as<uint64_t>()[n] = o;
-  memset(hs.as<char>() + o, 0, 16);
+  ho[n] = tot;
+  if ((rc = c.pin[SEQ].ensure(tot + 16))) return rc;
+  char* hs = c.pin[SEQ].as<char>();
+  parallel_for(n, 1024, threads, [&](size_t b, size_t e) {
+    for (size_t j = b; j < e; ++j) memcpy(hs + ho[j], seqs[idx[j]], lens[idx[j]]);
+  });
+  memset(hs + tot, 0, 16);
   const uint64_t cap = sa_minimize_out_capacity(n, tot, k, w);
   const size_t ws = sa_minimize_workspace_bytes(n, tot, maxl, k, w, variant);
-  DevBuf ds, doff, dout, dooff, dstatus, dws;
-  if ((rc = ds.alloc(tot + 16)) || (rc = doff.alloc((n + 1) * 8)) || (rc = dout.alloc(cap * 12)) ||
-      (rc = dooff.alloc((n + 1) * 8)) || (rc = dstatus.alloc(4)) || (rc = dws.alloc(ws)))
+  if ((rc = c.dev[SEQ].ensure(tot + 16)) || (rc = c.dev[OFF].ensure((n + 1) * 8)) || (rc = c.dev[OUT].ensure(cap * 12)) ||
+      (rc = c.dev[OOFF].ensure((n + 1) * 8)) || (rc = c.dev[STATUS].ensure(4)) || (rc = c.dev[WS].ensure(ws)))
     return rc;
-  SA_HIP_TRY(hipMemcpyAsync(ds.p, hs.p, tot + 16, hipMemcpyHostToDevice, st.s));
-  SA_HIP_TRY(hipMemcpyAsync(doff.p, ho.p, (n + 1) * 8, hipMemcpyHostToDevice, st.s));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[SEQ].p, hs, tot + 16, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[OFF].p, ho, (n + 1) * 8, hipMemcpyHostToDevice, st));
   sa_minimize_batch b{};
-  b.d_seq = ds.as<uint8_t>();
-  b.d_off = doff.as<uint64_t>();
+  b.d_seq = c.dev[SEQ].as<uint8_t>();
+  b.d_off = c.dev[OFF].as<uint64_t>();
   b.n = n;
   b.total_len = tot;
   b.max_len = maxl;
@@ -254,30 +357,39 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   b.k = k;
   b.w = w;
   b.variant = variant;
-  b.d_out = dout.as<uint32_t>();
+  b.d_out = c.dev[OUT].as<uint32_t>();
   b.out_capacity = cap;
-  b.d_out_off = dooff.as<uint64_t>();
-  b.d_status = dstatus.as<int>();
-  if ((rc = sa_minimize_batch_device(device, st.s, &b, dws.p, ws))) return rc;
-  std::vector<uint64_t> ooff(n + 1);
-  int status = 0;
-  SA_HIP_TRY(hipMemcpyAsync(ooff.data(), dooff.p, (n + 1) * 8, hipMemcpyDeviceToHost, st.s));
-  SA_HIP_TRY(hipMemcpyAsync(&status, dstatus.p, 4, hipMemcpyDeviceToHost, st.s));
-  SA_HIP_TRY(hipStreamSynchronize(st.s));
+  b.d_out_off = c.dev[OOFF].as<uint64_t>();
+  b.d_status = c.dev[STATUS].as<int>();
+  if ((rc = sa_minimize_batch_device(device, st, &b, c.dev[WS].p, ws))) return rc;
+  if ((rc = c.pin[OOFF].ensure((n + 1) * 8)) || (rc = c.pin[STATUS].ensure(4))) return rc;
+  const uint64_t* ooff = c.pin[OOFF].as<uint64_t>();
+  SA_HIP_TRY(hipMemcpyAsync(c.pin[OOFF].p, c.dev[OOFF].p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.pin[STATUS].p, c.dev[STATUS].p, 4, hipMemcpyDeviceToHost, st));
+  SA_HIP_TRY(hipStreamSynchronize(st));
+  const int status = *c.pin[STATUS].as<int>();
   if (status == SA_ERR_RANGE)
     return fail(SA_ERR_RANGE, "decimal Minimize: a k-mer value exceeds INT_MAX (stoi out of range)");
   if (status) return fail(status, "device reported status %d", status);
-  std::vector<uint32_t> all(ooff[n] * 3 + 3);
-  SA_HIP_TRY(hipMemcpyAsync(all.data(), dout.p, ooff[n] * 12, hipMemcpyDeviceToHost, st.s));
-  SA_HIP_TRY(hipStreamSynchronize(st.s));
-  for (uint32_t j = 0; j < n; ++j) {
-    const uint64_t c = ooff[j + 1] - ooff[j];
-    uint32_t* dst = (uint32_t*)malloc(c ? c * 12 : 4);
-    if (!dst) return fail(SA_ERR_ARGUMENT, "out of host memory");
-    memcpy(dst, all.data() + ooff[j] * 3, c * 12);
-    out_triples[idx[j]] = dst;
-    out_counts[idx[j]] = c;
-  }
+  if ((rc = c.pin[OUT].ensure(ooff[n] * 12 + 12))) return rc;
+  const uint32_t* all = c.pin[OUT].as<uint32_t>();
+  SA_HIP_TRY(hipMemcpyAsync(c.pin[OUT].p, c.dev[OUT].p, ooff[n] * 12, hipMemcpyDeviceToHost, st));
+  SA_HIP_TRY(hipStreamSynchronize(st));
+  std::atomic<bool> oom{false};
+  parallel_for(n, 1024, threads, [&](size_t b0, size_t e0) {
+    for (size_t j = b0; j < e0; ++j) {
+      const uint64_t cnt = ooff[j + 1] - ooff[j];
+      uint32_t* dst = (uint32_t*)malloc(cnt ? cnt * 12 : 4);
+      if (!dst) {
+        oom = true;
+        continue;
+      }
+      memcpy(dst, all + ooff[j] * 3, cnt * 12);
+      out_triples[idx[j]] = dst;
+      out_counts[idx[j]] = cnt;
+    }
+  });
+  if (oom) return fail(SA_ERR_ARGUMENT, "out of host memory");
   return SA_OK;
 }
 
@@ -286,7 +398,9 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
 std::vector<std::vector<uint32_t>> deal(const std::vector<uint64_t>& cost, int ndev, uint32_t block) {
   std::vector<uint32_t> order(cost.size());
   std::iota(order.begin(), order.end(), 0u);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  const bool uniform = std::all_of(cost.begin(), cost.end(), [&](uint64_t c) { return c == cost[0]; });
+  if (!uniform)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
   std::vector<std::vector<uint32_t>> shards(ndev);
   for (size_t i = 0; i < order.size(); ++i) shards[(i / block) % ndev].push_back(order[i]);
   return shards;
@@ -294,6 +408,7 @@ std::vector<std::vector<uint32_t>> deal(const std::vector<uint64_t>& cost, int n
 
 template <class F>
 int run_on_devices(int ndev, F f) {
+  if (ndev == 1) return f(0);  // on the caller's thread
   std::vector<int> rcs(ndev, SA_OK);
   std::vector<std::string> msgs(ndev);
   std::vector<std::thread> th;
@@ -362,9 +477,10 @@ int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
   for (size_t i = 0; i < n; ++i)
     cost[i] = ((uint64_t)target_lens[i] << 32) | query_lens[i];  // order by target, then query length
   const auto shards = deal(cost, ndev, 1024);
+  const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
   return run_on_devices(ndev, [&](int d) {
     return align_shard(d, shards[d], queries, query_lens, targets, target_lens, type, match, mismatch,
-                       gap, scores, target_begin, cigars);
+                       gap, scores, target_begin, cigars, threads);
   });
 }
 
@@ -379,8 +495,9 @@ int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t
   std::vector<uint64_t> cost(n);
   for (size_t i = 0; i < n; ++i) cost[i] = lens[i];
   const auto shards = deal(cost, ndev, 16);
+  const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
   return run_on_devices(ndev, [&](int d) {
-    return minimize_shard(d, shards[d], seqs, lens, k, w, variant, out_triples, out_counts);
+    return minimize_shard(d, shards[d], seqs, lens, k, w, variant, out_triples, out_counts, threads);
   });
 }
 
@@ -391,34 +508,37 @@ int sa_remove_duplicate_host(uint32_t* triples, size_t n, uint32_t* out, size_t*
   if (n > 0x7FFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many tuples");
   if (pick_devices(1) == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
   SA_HIP_TRY(hipSetDevice(0));
-  Stream st;
-  SA_HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
-  DevBuf din, dsorted, dflags, dpos, dout, dtmp;
+  Lease lease(0);
+  if (!lease.c) return fail(SA_ERR_HIP, "cannot create a stream on GPU 0");
+  HostContext& c = *lease.c;
+  hipStream_t st = c.stream;
+  enum { IN, SORTED, FLAGS, POS, OUT, TMP };
   int rc;
   const uint32_t m = (uint32_t)n;
-  if ((rc = din.alloc(n * 12)) || (rc = dsorted.alloc(n * 12)) || (rc = dflags.alloc((n + 1) * 4)) ||
-      (rc = dpos.alloc((n + 1) * 4)) || (rc = dout.alloc(n * 12)))
+  if ((rc = c.dev[IN].ensure(n * 12)) || (rc = c.dev[SORTED].ensure(n * 12)) || (rc = c.dev[FLAGS].ensure((n + 1) * 4)) ||
+      (rc = c.dev[POS].ensure((n + 1) * 4)) || (rc = c.dev[OUT].ensure(n * 12)))
     return rc;
-  SA_HIP_TRY(hipMemcpyAsync(din.p, triples, n * 12, hipMemcpyHostToDevice, st.s));
+  Triple* din = c.dev[IN].as<Triple>();
+  Triple* dsorted = c.dev[SORTED].as<Triple>();
+  uint32_t* dflags = c.dev[FLAGS].as<uint32_t>();
+  uint32_t* dpos = c.dev[POS].as<uint32_t>();
+  SA_HIP_TRY(hipMemcpyAsync(din, triples, n * 12, hipMemcpyHostToDevice, st));
   size_t t1 = 0, t2 = 0;
-  SA_HIP_TRY(rocprim::merge_sort(nullptr, t1, din.as<Triple>(), dsorted.as<Triple>(), n, TripleLess(), st.s));
-  SA_HIP_TRY(rocprim::exclusive_scan(nullptr, t2, dflags.as<uint32_t>(), dpos.as<uint32_t>(), 0u, n + 1,
-                                     rocprim::plus<uint32_t>(), st.s));
-  if ((rc = dtmp.alloc(std::max(t1, t2)))) return rc;
-  SA_HIP_TRY(rocprim::merge_sort(dtmp.p, t1, din.as<Triple>(), dsorted.as<Triple>(), n, TripleLess(), st.s));
-  hipLaunchKernelGGL(triple_flags, dim3((m + 256) / 256), dim3(256), 0, st.s, dsorted.as<Triple>(), m,
-                     dflags.as<uint32_t>());
-  SA_HIP_TRY(rocprim::exclusive_scan(dtmp.p, t2, dflags.as<uint32_t>(), dpos.as<uint32_t>(), 0u, n + 1,
-                                     rocprim::plus<uint32_t>(), st.s));
-  hipLaunchKernelGGL(triple_compact, dim3((m + 255) / 256), dim3(256), 0, st.s, dsorted.as<Triple>(),
-                     dflags.as<uint32_t>(), dpos.as<uint32_t>(), m, dout.as<Triple>());
+  SA_HIP_TRY(rocprim::merge_sort(nullptr, t1, din, dsorted, n, TripleLess(), st));
+  SA_HIP_TRY(rocprim::exclusive_scan(nullptr, t2, dflags, dpos, 0u, n + 1, rocprim::plus<uint32_t>(), st));
+  if ((rc = c.dev[TMP].ensure(std::max(t1, t2)))) return rc;
+  SA_HIP_TRY(rocprim::merge_sort(c.dev[TMP].p, t1, din, dsorted, n, TripleLess(), st));
+  hipLaunchKernelGGL(triple_flags, dim3((m + 256) / 256), dim3(256), 0, st, dsorted, m, dflags);
+  SA_HIP_TRY(rocprim::exclusive_scan(c.dev[TMP].p, t2, dflags, dpos, 0u, n + 1, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(triple_compact, dim3((m + 255) / 256), dim3(256), 0, st, dsorted, dflags, dpos, m,
+                     c.dev[OUT].as<Triple>());
   SA_HIP_TRY(hipGetLastError());
   uint32_t uniq = 0;
-  SA_HIP_TRY(hipMemcpyAsync(&uniq, dpos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st.s));
-  SA_HIP_TRY(hipMemcpyAsync(triples, dsorted.p, n * 12, hipMemcpyDeviceToHost, st.s));  // sorted in place
-  SA_HIP_TRY(hipStreamSynchronize(st.s));
-  SA_HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)uniq * 12, hipMemcpyDeviceToHost, st.s));
-  SA_HIP_TRY(hipStreamSynchronize(st.s));
+  SA_HIP_TRY(hipMemcpyAsync(&uniq, dpos + n, 4, hipMemcpyDeviceToHost, st));
+  SA_HIP_TRY(hipMemcpyAsync(triples, dsorted, n * 12, hipMemcpyDeviceToHost, st));  // sorted in place
+  SA_HIP_TRY(hipStreamSynchronize(st));
+  SA_HIP_TRY(hipMemcpyAsync(out, c.dev[OUT].p, (size_t)uniq * 12, hipMemcpyDeviceToHost, st));
+  SA_HIP_TRY(hipStreamSynchronize(st));
   *out_n = uniq;
   return SA_OK;
 }
