@@ -255,3 +255,22 @@ def test_cigar_stats_on_device_vs_text(oracle):
             assert (int(block[p]), ml) == (abl, 0)
             want = [sum(int(n) for n, o in re.findall(r"(\d+)([MXID])", cigars[p]) if o == op) for op in "MXID"]
             assert list(map(int, ops[p])) == want, cigars[p]
+
+
+def test_arbitrary_byte_alphabets_vs_oracle(oracle, family):
+    """Align() compares symbols as opaque bytes (src/alignment.cpp:63,176,281): protein-like alphabets and
+    raw bytes, NUL and values above 127 included, must behave like letters."""
+    rng = random.Random(77)
+    protein = b"ACDEFGHIKLMNPQRSTVWY"
+    anybyte = bytes(range(256))
+    pairs = []
+    for alpha in (protein, anybyte, b"\x00\xff\x80A"):
+        for _ in range(120):
+            T = rng.randint(1, 160)
+            t = bytes(rng.choice(alpha) for _ in range(T))
+            cut = t[rng.randint(0, T // 2):rng.randint(T // 2 + 1, T + 1)]
+            q = bytes(c if rng.random() > 0.15 else rng.choice(alpha) for c in cut) or alpha[:1]
+            pairs.append((q, t))
+    for (m, x, g) in ((1, -1, -1), (2, -3, -2)):
+        for typ in (0, 1, 2):
+            _run_group(_oracle_cases(oracle, pairs, typ, m, x, g))
