@@ -150,7 +150,9 @@ void sa_free(void* p);
  * Minimizers, device-resident batch.  Takes the place of one MinimizeBinary()/Minimize() call per
  * sequence (reference src/minimizer_binary.cpp:136-178, called at src/mapper.cpp:179).
  *
- * Sequence s is d_seq[off[s] .. off[s+1]) (ASCII, ACGT in either case).  Output: for each sequence its
+ * Sequence s is d_seq[off[s] .. off[s+1]) (ASCII; ACGT in either case are bases, any other byte counts as
+ * the reference's code -1, src/minimizer_binary.cpp:28-29 - SA_MIN_BINARY reproduces what that does to the
+ * k-mer values, a batch containing such bytes takes about 2.5 times as long).  Output: for each sequence its
  * minimizers sorted by (value, position, strand) with duplicates removed (reference
  * src/utility.cpp:8-26), as uint32 triples {value, position, strand(1 = forward, 0 = other strand)};
  * sequence s owns triples [d_out_off[s], d_out_off[s+1]) of d_out.  out_capacity is in triples;

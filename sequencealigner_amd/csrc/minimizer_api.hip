@@ -73,10 +73,14 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint32_t (*bufv)[kT
 // One thread per chunk: proves the chunk's entry state (exactly from the sequence start, or by collapsing
 // the candidate sets during the warm-up), runs the chunk's windows and writes their keys, adjacent
 // duplicates dropped.
-template <uint32_t W>
+// M = Machine<W>: the fast machine, exact as long as every byte is a base - it reports other bytes in
+// a.other.  M = MachineX: the exact machine for such batches; returns at once unless a.other is set.
+template <class M>
 __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unresolved) {
   __shared__ uint32_t bufv[kBuf][kThreads];  // buffered tuples: value
   __shared__ uint32_t bufp[kBuf][kThreads];  //                  position << 1 | strand
+  if (M::kExact && *a.other == 0) return;
+  uint32_t other = 0;
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = blockIdx.x * kThreads + tid;
   ChunkRef c;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   const uint32_t seq = valid ? c.seq : 0xFFFFFFFFu;
   const uint32_t slot = valid ? a.wbase[c.seq] : 0;
   const uint32_t k = a.k, w = a.w;
-  Machine<W> m;
+  M m;
   m.reset(k, w);
   uint32_t i = E;  // next window
   uint32_t cnt = 0;
@@ -106,14 +110,14 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   uint32_t Mf = 1, Mc = 1;
   if (valid) {
     if (F <= kWarm) {  // close to the sequence start: run the windows before the chunk exactly
-      for (uint32_t b = 0; b < w + k - 1; ++b) m.push(base_code(s[b]));
+      for (uint32_t b = 0; b < w + k - 1; ++b) m.push(M::feed1(s[b], other));
       m.first_window();
       if (F == 0) emit();
       i = 1;
     } else {  // candidates of step j are the positions j-k-1 .. j-1
       i = F - kWarm;
       const uint32_t j = i + w - 1;
-      for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(base_code(s[b]));
+      for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(M::feed1(s[b], other));
       m.j = j;
       m.init_window();
       Mf = Mc = (2u << k) - 1u;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   for (uint32_t guard = 0; guard < kWarm; ++guard) {
     if (!__any(sets && (__builtin_popcount(Mf) != 1 || __builtin_popcount(Mc) != 1))) break;
     if (sets) {
-      m.step_sets(base_code(s[m.j + k - 1]), Mf, Mc);
+      m.step_sets(M::feed1(s[m.j + k - 1], other), Mf, Mc);
       ++i;
     }
   }
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
     const uint32_t max_align = wave_max_u32(align);
     for (uint32_t u = 0; u < max_align; ++u) {
       if (u < align) {
-        m.step(base_code(s[m.j + k - 1]));
+        m.step(M::feed1(s[m.j + k - 1], other));
         ++i;
       }
     }
@@ -152,18 +156,18 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   uint64_t word = rem ? load8(next_base) : 0;
   for (uint32_t g = 0; g < max_groups; ++g) {
     if (g < groups) {
-      const uint32_t c0 = base_code4((uint32_t)word), c1 = base_code4((uint32_t)(word >> 32));
+      const uint32_t c0 = M::feed4((uint32_t)word, other), c1 = M::feed4((uint32_t)(word >> 32), other);
       next_base += 8;
       if (g + 1 < groups || tail) word = load8(next_base);
       if (i >= F) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 3u);
+          m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & M::kFeedMask);
           emit();
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 3u);
+        for (int u = 0; u < 8; ++u) m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & M::kFeedMask);
       }
       i += 8;
     }
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   }
   for (uint32_t u = 0; u < max_tail; ++u) {
     if (u < tail) {
-      m.step(base_code((uint32_t)(word >> (8 * u)) & 0xFFu));
+      m.step(M::feed1((uint32_t)(word >> (8 * u)) & 0xFFu, other));
       emit();
     }
   }
@@ -182,12 +186,22 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
     a.resolved[chunk] = live ? 1 : 0;
     if (!live) atomicAdd(n_unresolved, 1u);
   }
+  if (!M::kExact && other) atomicOr(a.other, 1u);
+}
+
+// Before the exact machine runs a batch again: forget the keys and the unresolved chunks of the first run.
+__global__ void min_redo_reset(uint32_t* counter, uint32_t n, const uint32_t* other) {
+  if (*other == 0) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) counter[i] = 0;  // n counters and the count of unresolved chunks behind them
 }
 
 // One wave per sequence, only when some chunk's candidate set did not collapse: those chunks take their
 // entry state from the (final) exit state of the chunk before them, in order.  Lane 0 runs the machine.
+template <class M>
 __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n_unresolved) {
   if (*n_unresolved == 0) return;
+  if (M::kExact && *a.other == 0) return;
   const uint32_t s = (blockIdx.x * kThreads + threadIdx.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   if (s >= a.n) return;
@@ -205,15 +219,16 @@ __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n
       if (lane == 0) {
         const uint32_t F = (chunk - c_begin) * a.chunk;
         const uint32_t E = F + a.chunk < windows ? F + a.chunk : windows;
-        Machine<0> m;
+        M m;
+        uint32_t other = 0;  // the run kernel has looked at every byte already
         m.reset(k, w);
         const uint32_t j = F + w - 1;
-        for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(base_code(seq[b]));
+        for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(M::feed1(seq[b], other));
         m.enter(j, a.exit_f[chunk - 1], a.exit_c[chunk - 1]);
         uint32_t n_out = a.counter[s];
         uint64_t last = ~0ull;
         for (uint32_t i = F; i < E; ++i) {
-          m.step(base_code(seq[m.j + k - 1]));
+          m.step(M::feed1(seq[m.j + k - 1], other));
           const uint64_t key = m.key(a.key_shift);
           if (key != last) {
             out[n_out++] = key;
@@ -607,7 +622,9 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   }
   pl->max_chunks = (uint32_t)(total_len / pl->chunk + n);
   pl->max_tiles = (uint32_t)(pl->capacity / kTile + n);
-  const uint32_t value_bits = (variant == SA_MIN_BINARY) ? 2 * k : 31;
+  // w = 1 can emit k-mer 0, whose value the reference builds without the mask: with a non-base byte in it
+  // the value has ones above its 2k bits
+  const uint32_t value_bits = (variant == SA_MIN_BINARY) ? (w == 1 ? 32 : 2 * k) : 31;
   pl->key_shift = bits_for(max_len) + 1;
   pl->end_bit = pl->key_shift + value_bits;
   if (pl->end_bit > 64) return SA_ERR_ARGUMENT;
@@ -634,7 +651,7 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_chunk_base = take(n1);
   pl->o_windows = take(n1);
   pl->o_wbase = take(n1);
-  pl->o_counter = take(n1 + 4);  // n counters, the count of unresolved chunks, the count of long sequences
+  pl->o_counter = take(n1 + 8);  // n counters, unresolved chunks, long sequences, "bytes other than bases seen"
   pl->o_exit_f = take(mc * 4);
   pl->o_exit_c = take(mc * 4);
   pl->o_resolved = take(mc);
@@ -704,6 +721,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   uint32_t* counter = (uint32_t*)(ws + pl.o_counter);
   uint32_t* n_unresolved = counter + b->n;
   uint32_t* n_big = counter + b->n + 1;
+  uint32_t* other = counter + b->n + 2;
   uint64_t* keys = (uint64_t*)(ws + pl.o_keys);
   uint64_t* sorted = (uint64_t*)(ws + pl.o_sorted);
   uint32_t* seg_begin = (uint32_t*)(ws + pl.o_seg_begin);
@@ -731,8 +749,9 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.resolved = (uint8_t*)(ws + pl.o_resolved);
   a.keys = keys;
   a.status = b->d_status;
+  a.other = other;
   if (b->d_status) SA_HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), stream));
-  SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 2) * 4, stream));
+  SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 3) * 4, stream));
   SA_HIP_TRY(hipMemsetAsync(tile_count, 0, ((size_t)pl.max_tiles + 1) * 4, stream));
 
   auto blocks = [](uint64_t items) { return dim3((unsigned)((items + kThreads - 1) / kThreads)); };
@@ -745,9 +764,17 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, windows, wbase, 0u, (size_t)b->n + 1,
                                      rocprim::plus<uint32_t>(), stream));
   if (b->variant == SA_MIN_BINARY) {
-    auto* run = b->w == 5 ? min_run<5> : b->w == 10 ? min_run<10> : min_run<0>;
+    auto* run = b->w == 5 ? min_run<Machine<5>> : b->w == 10 ? min_run<Machine<10>> : min_run<Machine<0>>;
     hipLaunchKernelGGL(run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
-    hipLaunchKernelGGL(min_fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
+    hipLaunchKernelGGL(min_fix<Machine<0>>, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a,
+                       n_unresolved);
+    // a batch with bytes other than bases runs again on the exact machine (the three kernels return at
+    // once otherwise)
+    hipLaunchKernelGGL(min_redo_reset, blocks((uint64_t)b->n + 1), dim3(kThreads), 0, stream, counter, b->n,
+                       other);
+    hipLaunchKernelGGL(min_run<MachineX>, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
+    hipLaunchKernelGGL(min_fix<MachineX>, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a,
+                       n_unresolved);
   } else {
     hipLaunchKernelGGL(dec_run, blocks(b->n), dim3(kThreads), 0, stream, a);
   }

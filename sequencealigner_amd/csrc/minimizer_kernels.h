@@ -10,7 +10,10 @@
 //   * window i = 0 starts from the leftmost strict minimum of V[0 .. w-1] (:149-150), window i >= 1
 //     performs the step j = i + w - 1 (:161-164); each window emits the forward minimum when its value
 //     is strictly smaller than the other strand's, else the other strand's (:153-158, 167-172);
-//   * the emitted (value, position, strand) tuples are sorted and de-duplicated (src/utility.cpp:8-26).
+//   * the emitted (value, position, strand) tuples are sorted and de-duplicated (src/utility.cpp:8-26);
+//   * any other byte has code -1 on both strands (:28-29, :46-47): OR-ed into the value it sets every bit,
+//     so a k-mer reads as 3s from its first base up to its last such byte; k-mer 0 is built without the
+//     mask (:53-60) and keeps the ones above its 2k bits.
 //
 // The state machine is sequential, so a sequence is cut into chunks of `chunk` windows, one thread per
 // chunk.  Invariant (for w <= k + 1): before step j the state lies in [j-k-1, j-1], i.e. at most k+1
@@ -22,7 +25,9 @@
 //
 // All k-mer values a step can need lie in the last 2k bases, so the history is one 64-bit register pair
 // and every value is a shift and a mask.  The other strand is never materialised: its order is the
-// reverse of the forward order, so its minimum is the forward maximum.
+// reverse of the forward order, so its minimum is the forward maximum.  That identity needs every byte to
+// be a base: Machine only notices other bytes (other4 / other1), and a batch that has any is run again
+// with MachineX, which carries a second history of "not a base" marks and both strands' values.
 #ifndef SA_MINIMIZER_KERNELS_H
 #define SA_MINIMIZER_KERNELS_H
 
@@ -49,6 +54,7 @@ struct MinArgs {
   uint8_t* resolved;           // per chunk: 1 once its keys are written and its exit state is final
   uint64_t* keys;              // candidate keys; sequence s owns [wbase[s], wbase[s] + counter[s])
   int* status;
+  uint32_t* other;             // set to 1 by a thread that met a byte other than ACGT / acgt
 };
 
 // forward-strand code of an ASCII base: C0 A1 T2 G3 (either case).  (c >> 1) & 3 gives A0 C1 T2 G3.
@@ -63,6 +69,16 @@ __device__ __forceinline__ uint32_t base_code4(uint32_t c) {
   return x ^ ((~x >> 1) & 0x01010101u);
 }
 
+// Nonzero when one of the 4 bytes of `c` is not one of ACGT / acgt: (c >> 1) & 3 names the base a byte
+// would be (A0 C1 T2 G3), a byte permute fetches that letter, the upper-cased byte must equal it.
+__device__ __forceinline__ uint32_t other4(uint32_t c) {
+  const uint32_t x = (c >> 1) & 0x03030303u;
+  return __builtin_amdgcn_perm(0u, 0x47544341u, x) ^ (c & 0xDFDFDFDFu);
+}
+__device__ __forceinline__ uint32_t other1(uint32_t c) {
+  return ((0x47544341u >> (8 * ((c >> 1) & 3u))) & 0xFFu) ^ (c & 0xDFu);
+}
+
 __device__ __forceinline__ uint64_t make_key(uint32_t value, uint32_t pos, uint32_t strand,
                                              uint32_t shift) {
   return ((uint64_t)value << shift) | ((uint64_t)pos << 1) | strand;
@@ -72,6 +88,19 @@ __device__ __forceinline__ uint64_t make_key(uint32_t value, uint32_t pos, uint3
 // over the window unrolls); W = 0 takes it from reset().
 template <uint32_t W>
 struct Machine {
+  // how the kernels feed bases: feed1 / feed4 turn 1 / 4 bytes into the per-base argument(s) of push() and
+  // step() (8 bits apart in feed4), kFeedMask extracts one; `other` collects evidence of non-base bytes
+  static constexpr bool kExact = false;  // false: results are valid only while `other` stays 0
+  static constexpr uint32_t kFeedMask = 3u;
+  __device__ static __forceinline__ uint32_t feed1(uint32_t byte, uint32_t& other) {
+    other |= other1(byte);
+    return base_code(byte);
+  }
+  __device__ static __forceinline__ uint32_t feed4(uint32_t bytes, uint32_t& other) {
+    other |= other4(bytes);
+    return base_code4(bytes);
+  }
+
   uint32_t lo, hi;          // the last 32 base codes, newest in the low bits of lo
   uint32_t pf, vf, pc, vc;  // per strand: position of the minimum and its FORWARD value
   uint32_t j;               // k-mer the next step brings in (the step consumes base j + k - 1)
@@ -211,6 +240,151 @@ struct Machine {
     for (uint32_t rest = Mc & low; rest; rest &= rest - 1) {
       const uint32_t o = __builtin_ctz(rest);
       oc |= (vj > value_back(o + 1)) ? 1u : (2u << o);
+    }
+    Mf = of;
+    Mc = oc;
+    ++j;
+  }
+};
+
+// The state machine for sequences with bytes other than bases: same interface as Machine, both strands'
+// values explicit.  A second history holds a mark (binary 11) for every such byte; a k-mer's value is its
+// codes OR-ed with ones from its newest mark upwards - within the 2k-bit mask, except for k-mer 0.
+struct MachineX {
+  static constexpr bool kExact = true;
+  static constexpr uint32_t kFeedMask = 7u;  // code | mark << 2
+  __device__ static __forceinline__ uint32_t feed1(uint32_t byte, uint32_t& other) {
+    (void)other;
+    return base_code(byte) | (other1(byte) ? 4u : 0u);
+  }
+  __device__ static __forceinline__ uint32_t feed4(uint32_t bytes, uint32_t& other) {
+    (void)other;
+    const uint32_t o = other4(bytes);
+    // 0x04 in every byte of o that is not zero
+    const uint32_t nz = (((o & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | o) & 0x80808080u;
+    return base_code4(bytes) | (nz >> 5);
+  }
+
+  uint32_t lo, hi, mlo, mhi;  // codes and marks of the last 32 bytes, newest in the low bits
+  uint32_t pf, vf, pc, vc;    // per strand: position of the minimum and the strand's own value
+  uint32_t j, k, w, mask;
+
+  __device__ __forceinline__ void reset(uint32_t k_, uint32_t w_) {
+    k = k_;
+    w = w_;
+    mask = (k_ >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k_)) - 1u);
+    lo = hi = mlo = mhi = 0;
+    pf = pc = vf = vc = j = 0;
+  }
+  __device__ __forceinline__ void push(uint32_t fed) {
+    hi = __builtin_amdgcn_alignbit(hi, lo, 30);
+    lo = (lo << 2) | (fed & 3u);
+    mhi = __builtin_amdgcn_alignbit(mhi, mlo, 30);
+    mlo = (mlo << 2) | ((fed & 4u) ? 3u : 0u);
+  }
+  // Both strands' values of k-mer `index`, which starts `back` positions before the newest complete one.
+  __device__ __forceinline__ void values(uint32_t back, uint32_t index, uint32_t* f, uint32_t* c) const {
+    const uint32_t raw = (uint32_t)((((uint64_t)hi << 32) | lo) >> (2 * back)) & mask;
+    const uint32_t marks = (uint32_t)((((uint64_t)mhi << 32) | mlo) >> (2 * back)) & mask;
+    uint32_t ones = marks ? 0u - (marks & (0u - marks)) : 0u;  // from the newest mark upwards
+    if (index != 0) ones &= mask;
+    *f = raw | ones;
+    *c = (mask - raw) | ones;
+  }
+  // Leftmost strict minima of the w k-mers first .. first + w - 1; the newest complete k-mer is `newest`.
+  __device__ __forceinline__ void scan(uint32_t first, uint32_t newest, uint32_t* pmin_f, uint32_t* vmin_f,
+                                       uint32_t* pmin_c, uint32_t* vmin_c) const {
+    uint32_t a, b;
+    values(newest - first, first, &a, &b);
+    uint32_t pa = first, pb = first;
+    for (uint32_t t = 1; t < w; ++t) {
+      uint32_t f, c;
+      values(newest - first - t, first + t, &f, &c);
+      if (f < a) {
+        a = f;
+        pa = first + t;
+      }
+      if (c < b) {
+        b = c;
+        pb = first + t;
+      }
+    }
+    *pmin_f = pa;
+    *vmin_f = a;
+    *pmin_c = pb;
+    *vmin_c = b;
+  }
+  __device__ __forceinline__ void init_window() {}
+  __device__ __forceinline__ void first_window() {  // bases 0 .. w+k-2 pushed: newest k-mer w - 1
+    scan(0, w - 1, &pf, &vf, &pc, &vc);
+    j = w;
+  }
+  __device__ __forceinline__ void enter(uint32_t j_, uint32_t pf_, uint32_t pc_) {  // newest k-mer j_ - 1
+    uint32_t unused;
+    j = j_;
+    pf = pf_;
+    pc = pc_;
+    values(j_ - 1 - pf_, pf_, &vf, &unused);
+    values(j_ - 1 - pc_, pc_, &unused, &vc);
+  }
+  __device__ __forceinline__ void step(uint32_t fed) {
+    push(fed);
+    uint32_t vjf, vjc;
+    values(0, j, &vjf, &vjc);
+    const uint32_t expiring = j - k - 1;  // unsigned, as in the reference
+    const bool ef = pf == expiring, ec = pc == expiring;
+    if (ef || ec) {
+      uint32_t qf, rf, qc, rc;
+      scan(j - k, j, &qf, &rf, &qc, &rc);
+      if (ef) {
+        pf = qf;
+        vf = rf;
+      }
+      if (ec) {
+        pc = qc;
+        vc = rc;
+      }
+    }
+    if (!ef && vjf < vf) {
+      pf = j;
+      vf = vjf;
+    }
+    if (!ec && vjc < vc) {
+      pc = j;
+      vc = vjc;
+    }
+    ++j;
+  }
+  __device__ __forceinline__ void tuple(uint32_t* value, uint32_t* pos2) const {
+    const bool f = vf < vc;
+    *value = f ? vf : vc;
+    *pos2 = f ? (pf << 1 | 1u) : (pc << 1);
+  }
+  __device__ __forceinline__ uint64_t key(uint32_t shift) const {
+    uint32_t value, pos2;
+    tuple(&value, &pos2);
+    return ((uint64_t)value << shift) | pos2;
+  }
+  // One step for sets of candidate states (see Machine::step_sets).
+  __device__ __forceinline__ void step_sets(uint32_t fed, uint32_t& Mf, uint32_t& Mc) {
+    push(fed);
+    uint32_t vjf, vjc, qf, rf, qc, rc;
+    values(0, j, &vjf, &vjc);
+    scan(j - k, j, &qf, &rf, &qc, &rc);
+    const uint32_t low = (1u << k) - 1u;
+    uint32_t of = ((Mf >> k) & 1u) ? 1u << (j - qf) : 0u;  // offset in the next frame
+    uint32_t oc = ((Mc >> k) & 1u) ? 1u << (j - qc) : 0u;
+    for (uint32_t rest = Mf & low; rest; rest &= rest - 1) {
+      const uint32_t o = __builtin_ctz(rest);
+      uint32_t f, c;
+      values(o + 1, j - 1 - o, &f, &c);
+      of |= (vjf < f) ? 1u : (2u << o);
+    }
+    for (uint32_t rest = Mc & low; rest; rest &= rest - 1) {
+      const uint32_t o = __builtin_ctz(rest);
+      uint32_t f, c;
+      values(o + 1, j - 1 - o, &f, &c);
+      oc |= (vjc < c) ? 1u : (2u << o);
     }
     Mf = of;
     Mc = oc;

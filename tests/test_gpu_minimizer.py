@@ -116,3 +116,47 @@ def test_mixed_lengths_and_chunk_sizes_vs_oracle(oracle, chunk, monkeypatch):
         res = minimize.minimize_batch(seqs, k, w)
         for s, r in zip(seqs, res):
             assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s), chunk)
+
+
+def _with_other_bytes(rng, L, alpha):
+    s = [rng.choice(alpha) for _ in range(L)]
+    for _ in range(rng.randint(1, 4)):           # runs of N, some long, some at the very start
+        a = rng.choice([0, rng.randint(0, L - 1)])
+        for x in range(a, min(L, a + rng.choice([1, 1, 2, 7, 40, 400]))):
+            s[x] = "N"
+    return "".join(s)
+
+
+def test_bytes_other_than_bases_vs_oracle(oracle):
+    """The reference gives every byte that is not one of ACGT / acgt the code -1, which sets all bits of the
+    k-mer value (src/minimizer_binary.cpp:28-29, 46-47, 62-68), and builds k-mer 0 without the mask (:53-60).
+    The restatement agrees with the compiled reference on such input (tests/test_oracle_vs_reference.py);
+    here the GPU path must agree with the restatement: clean and unclean sequences in one batch, w = 1,
+    k = 16, long runs, chunked long sequences."""
+    from sequencealigner_amd import minimize
+    rng = random.Random(1234)
+    for _ in range(30):
+        k = rng.randint(1, 16)
+        w = rng.choice([1, rng.randint(1, k + 1)])
+        seqs = []
+        for _ in range(rng.randint(1, 40)):
+            L = rng.randint(k + w - 1, k + w - 1 + rng.choice([0, 5, 200, 3000, 9000]))
+            alpha = rng.choice(["ACGT", "ACGTN", "acgtn", "ACGTRYKMSW*-", "AC"])
+            s = "".join(rng.choice(alpha) for _ in range(L))
+            if rng.random() < 0.5:
+                s = _with_other_bytes(rng, L, "ACGT")
+            seqs.append(s)
+        res = minimize.minimize_batch(seqs, k, w)
+        for s, r in zip(seqs, res):
+            assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s), s[:80])
+
+
+def test_long_sequence_with_gaps_of_n_vs_oracle(oracle):
+    from sequencealigner_amd import minimize, synth
+    g = bytearray(synth.genome(700_000, seed=91))
+    for a, n in ((0, 30), (5_000, 1), (123_456, 20_000), (400_000, 3), (400_020, 1), (699_990, 10)):
+        g[a:a + n] = b"N" * n
+    g = bytes(g)
+    for k, w in ((15, 5), (16, 17), (8, 1)):
+        got = minimize.minimize_binary(g, k, w)
+        assert np.array_equal(got, oracle.minimize_binary_array(g, k, w)), (k, w)

@@ -49,6 +49,23 @@ def test_minimize_binary_differential(oracle, reference_lib):
         assert oracle.minimize_binary(s, k, w) == reference_lib.minimize_binary(s, k, w), (s, k, w)
 
 
+def test_minimize_binary_other_bytes_differential(oracle, reference_lib):
+    """Bytes that are not bases get the code -1 in the reference (src/minimizer_binary.cpp:28-29, 46-47): the
+    restatement must follow it there too (this pins the checker the GPU tests use for such input)."""
+    rng = random.Random(31)
+    for _ in range(1500):
+        k = rng.randint(1, 16)
+        w = rng.randint(1, k + 1)
+        L = rng.randint(k + w - 1, 300)
+        alpha = rng.choice(["ACGTN", "ACGTNacgtn", "ACGTRYKM", "ACGT" * 10 + "N"])
+        s = "".join(rng.choice(alpha) for _ in range(L))
+        if rng.random() < 0.3:
+            a = rng.randint(0, L - 1)
+            b = min(L, a + rng.randint(1, 40))
+            s = s[:a] + "N" * (b - a) + s[b:]
+        assert oracle.minimize_binary(s, k, w) == reference_lib.minimize_binary(s, k, w), (s, k, w)
+
+
 def test_minimize_binary_long_differential(oracle, reference_lib):
     g = bytes(synth.genome(300000, seed=31)) + b"T" * 5000 + bytes(synth.genome(1000, seed=32))
     a = oracle.minimize_binary_array(g, 15, 5)
