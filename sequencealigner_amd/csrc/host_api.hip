@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -127,6 +128,18 @@ unsigned host_threads() {
   return n;
 }
 
+// SA_HOST_TRACE=1 prints the wall time of each stage of a shard to stderr.
+struct StageTimer {
+  bool on = getenv("SA_HOST_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sa host] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 // f(begin, end) over [0, n) on up to `threads` host threads, at least `grain` items each.
 template <class F>
 void parallel_for(size_t n, size_t grain, unsigned threads, F f) {
@@ -180,11 +193,12 @@ char* runs_to_text(const uint32_t* runs, uint32_t n) {
   return out;
 }
 
-// One GPU's share of an alignment batch; `threads` host threads may help with staging and text.
+// One GPU's share of an alignment batch, or one of `mem_share` parts of it that run side by side on the
+// GPU; `threads` host threads may help with staging and text.
 int align_shard(int device, const std::vector<uint32_t>& idx, const char* const* queries,
                 const uint32_t* qlens, const char* const* targets, const uint32_t* tlens, int type,
                 int match, int mismatch, int gap, int32_t* scores, uint32_t* target_begin,
-                char** cigars, unsigned threads) {
+                char** cigars, unsigned threads, unsigned mem_share) {
   const uint32_t n = (uint32_t)idx.size();
   if (!n) return SA_OK;
   SA_HIP_TRY(hipSetDevice(device));
@@ -194,6 +208,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   hipStream_t st = c.stream;
   enum { Q, T, QO, TO, SCORE, TB, NRUNS, RUNS, OFF, WS, COMPACT };
 
+  StageTimer trace;
   // pinned staging: offsets first, then the sequences (8 bytes of slack: the kernels read aligned 8-byte words)
   int rc;
   if ((rc = c.pin[QO].ensure((n + 1) * 8)) || (rc = c.pin[TO].ensure((n + 1) * 8))) return rc;
@@ -214,6 +229,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   }
   hqo[n] = qtot;
   hto[n] = ttot;
+  trace.mark("offsets");
   if ((rc = c.pin[Q].ensure(qtot + 16)) || (rc = c.pin[T].ensure(ttot + 16))) return rc;
   char* hq = c.pin[Q].as<char>();
   char* ht = c.pin[T].as<char>();
@@ -226,6 +242,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   });
   memset(hq + qtot, 0, 16);
   memset(ht + ttot, 0, 16);
+  trace.mark("staging");
 
   const uint64_t stride = (uint64_t)maxq + maxt;
   const bool want_cigar = cigars != nullptr;
@@ -263,11 +280,13 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   if (ws > c.dev[WS].cap) {  // a workspace kept from an earlier call serves as long as it holds one pass
     size_t free_b = 0, total_b = 0;
     SA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = (size_t)((free_b + c.dev[WS].cap) * 0.8);
+    const size_t budget = (size_t)((free_b + c.dev[WS].cap) * 0.8 / mem_share);  // shards running side by side
     if (ws > budget) ws = std::max(min_ws, budget / min_ws * min_ws);
     if ((rc = c.dev[WS].ensure(ws))) return rc;
   }
+  trace.mark("buffers + copies queued");
   if ((rc = sa_align_batch_device(device, st, &b, c.dev[WS].p, c.dev[WS].cap))) return rc;
+  trace.mark("kernels queued");
 
   if ((rc = c.pin[SCORE].ensure(n * 4)) || (rc = c.pin[TB].ensure(n * 4)) || (rc = c.pin[NRUNS].ensure(n * 4)))
     return rc;
@@ -278,10 +297,12 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   if (b.d_target_begin) SA_HIP_TRY(hipMemcpyAsync(c.pin[TB].p, c.dev[TB].p, n * 4, hipMemcpyDeviceToHost, st));
   if (want_cigar) SA_HIP_TRY(hipMemcpyAsync(c.pin[NRUNS].p, c.dev[NRUNS].p, n * 4, hipMemcpyDeviceToHost, st));
   SA_HIP_TRY(hipStreamSynchronize(st));
+  trace.mark("device done");
   for (uint32_t j = 0; j < n; ++j) {
     scores[idx[j]] = hscore[j];
     if (target_begin) target_begin[idx[j]] = htb[j];
   }
+  trace.mark("scores scattered");
   if (want_cigar) {
     // compact the runs on the device, then one copy back
     if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
@@ -298,6 +319,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
     SA_HIP_TRY(hipGetLastError());
     SA_HIP_TRY(hipMemcpyAsync(c.pin[RUNS].p, c.dev[COMPACT].p, off[n] * 4, hipMemcpyDeviceToHost, st));
     SA_HIP_TRY(hipStreamSynchronize(st));
+    trace.mark("runs copied");
     const uint32_t* runs = c.pin[RUNS].as<uint32_t>();
     std::atomic<bool> oom{false};
     parallel_for(n, 4096, threads, [&](size_t b0, size_t e0) {
@@ -307,6 +329,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
       }
     });
     if (oom) return fail(SA_ERR_ARGUMENT, "out of host memory");
+    trace.mark("CIGAR text");
   }
   return SA_OK;
 }
@@ -407,7 +430,7 @@ std::vector<std::vector<uint32_t>> deal(const std::vector<uint64_t>& cost, int n
 }
 
 template <class F>
-int run_on_devices(int ndev, F f) {
+int run_on_devices(int ndev, F f) {  // ndev tasks, one host thread each
   if (ndev == 1) return f(0);  // on the caller's thread
   std::vector<int> rcs(ndev, SA_OK);
   std::vector<std::string> msgs(ndev);
@@ -419,7 +442,7 @@ int run_on_devices(int ndev, F f) {
     });
   for (auto& t : th) t.join();
   for (int d = 0; d < ndev; ++d)
-    if (rcs[d]) return fail(rcs[d], "GPU %d: %s", d, msgs[d].c_str());
+    if (rcs[d]) return fail(rcs[d], "shard %d: %s", d, msgs[d].c_str());
   return SA_OK;
 }
 
@@ -476,11 +499,23 @@ int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
   std::vector<uint64_t> cost(n);
   for (size_t i = 0; i < n; ++i)
     cost[i] = ((uint64_t)target_lens[i] << 32) | query_lens[i];  // order by target, then query length
-  const auto shards = deal(cost, ndev, 1024);
-  const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
-  return run_on_devices(ndev, [&](int d) {
-    return align_shard(d, shards[d], queries, query_lens, targets, target_lens, type, match, mismatch,
-                       gap, scores, target_begin, cigars, threads);
+  auto shards = deal(cost, ndev, 1024);
+  // Large shards are cut into parts that run as independent calls on streams of their own: one part's
+  // copies overlap another part's kernels, and staging and CIGAR text of the parts proceed in parallel.
+  size_t largest = 0;
+  for (const auto& sh : shards) largest = std::max(largest, sh.size());
+  const unsigned parts = largest >= 262144 ? 4 : largest >= 65536 ? 2 : 1;
+  if (parts > 1) {
+    std::vector<std::vector<uint32_t>> cut;
+    for (const auto& sh : shards)
+      for (unsigned p = 0; p < parts; ++p)
+        cut.emplace_back(sh.begin() + sh.size() * p / parts, sh.begin() + sh.size() * (p + 1) / parts);
+    shards.swap(cut);
+  }
+  const unsigned threads = std::max(1u, host_threads() / (unsigned)(ndev * parts));
+  return run_on_devices(ndev * parts, [&](int task) {
+    return align_shard(task / parts, shards[task], queries, query_lens, targets, target_lens, type, match,
+                       mismatch, gap, scores, target_begin, cigars, threads, parts);
   });
 }
 

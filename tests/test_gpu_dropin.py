@@ -82,3 +82,28 @@ def test_minimize_batch_host_and_remove_duplicate(oracle):
     capi.check(lib.sa_remove_duplicate_host(buf.ctypes.data, len(buf), out.ctypes.data, C.byref(m)))
     assert [tuple(int(v) for v in r) for r in buf] == want_sorted
     assert [tuple(int(v) for v in r) for r in out[:m.value]] == want_uniq
+
+
+def test_align_batch_host_large_batch_in_parts():
+    """Above 65 536 pairs the host entry point cuts a GPU's share into parts that run side by side; scores,
+    target_begin and CIGAR strings must equal those of the device-resident batch call."""
+    from sequencealigner_amd import align, capi, synth
+    lib = capi.lib()
+    n = 70_000
+    q, t = synth.pairs_short_read_window(n, seed=9, read_len=40, window_len=70)
+    q, t = np.ascontiguousarray(q), np.ascontiguousarray(t)
+    want_s, want_c, want_tb = align.align_batch(q, t, 1, 1, -1, -1)
+    qp = (C.c_char_p * n)(*[C.c_char_p(q.ctypes.data + i * q.shape[1]) for i in range(n)])
+    tp = (C.c_char_p * n)(*[C.c_char_p(t.ctypes.data + i * t.shape[1]) for i in range(n)])
+    ql = (C.c_uint32 * n)(*([q.shape[1]] * n))
+    tl = (C.c_uint32 * n)(*([t.shape[1]] * n))
+    scores = (C.c_int32 * n)()
+    tb = (C.c_uint32 * n)()
+    cig = (C.c_void_p * n)()
+    capi.check(lib.sa_align_batch_host(qp, ql, tp, tl, n, 1, 1, -1, -1, 1, scores, tb, cig))
+    assert np.array_equal(np.ctypeslib.as_array(scores), want_s)
+    assert np.array_equal(np.ctypeslib.as_array(tb), want_tb)
+    for i in range(n):
+        if i % 7 == 0:
+            assert C.cast(cig[i], C.c_char_p).value.decode() == want_c[i], i
+        lib.sa_free(cig[i])
