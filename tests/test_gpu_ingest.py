@@ -140,3 +140,14 @@ def test_ingested_reads_feed_the_minimizer_call(oracle):
     got = b.results()
     for i in (0, 17, 299):
         assert [tuple(int(v) for v in t) for t in got[i]] == oracle.minimize_binary(seqs[i], 15, 5)
+
+
+def test_files_of_tens_of_megabytes_vs_restatement(oracle):
+    """Tens of thousands of tiles: the scan over the tile summaries runs over many blocks."""
+    rng = np.random.default_rng(33)
+    data, names, seqs = seqfiles.fasta(rng, [int(x) for x in rng.integers(1, 15000, 3000)], width=80)
+    assert len(data) > 20_000_000
+    _check(oracle, data, 0, names, seqs)
+    data, names, seqs = seqfiles.fastq(rng, [int(x) for x in rng.integers(50, 9000, 2500)])
+    assert len(data) > 20_000_000
+    _check(oracle, data, 1, names, seqs)
