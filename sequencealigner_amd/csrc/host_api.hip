@@ -345,6 +345,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   HostContext& c = *lease.c;
   hipStream_t st = c.stream;
   enum { SEQ, OFF, OUT, OOFF, STATUS, WS };
+  StageTimer trace;
   int rc;
   if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
   uint64_t* ho = c.pin[OFF].as<uint64_t>();
@@ -363,6 +364,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
     for (size_t j = b; j < e; ++j) memcpy(hs + ho[j], seqs[idx[j]], lens[idx[j]]);
   });
   memset(hs + tot, 0, 16);
+  trace.mark("staging");
   const uint64_t cap = sa_minimize_out_capacity(n, tot, k, w);
   const size_t ws = sa_minimize_workspace_bytes(n, tot, maxl, k, w, variant);
   if ((rc = c.dev[SEQ].ensure(tot + 16)) || (rc = c.dev[OFF].ensure((n + 1) * 8)) || (rc = c.dev[OUT].ensure(cap * 12)) ||
@@ -384,12 +386,15 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   b.out_capacity = cap;
   b.d_out_off = c.dev[OOFF].as<uint64_t>();
   b.d_status = c.dev[STATUS].as<int>();
+  trace.mark("buffers + copies queued");
   if ((rc = sa_minimize_batch_device(device, st, &b, c.dev[WS].p, ws))) return rc;
+  trace.mark("kernels queued");
   if ((rc = c.pin[OOFF].ensure((n + 1) * 8)) || (rc = c.pin[STATUS].ensure(4))) return rc;
   const uint64_t* ooff = c.pin[OOFF].as<uint64_t>();
   SA_HIP_TRY(hipMemcpyAsync(c.pin[OOFF].p, c.dev[OOFF].p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
   SA_HIP_TRY(hipMemcpyAsync(c.pin[STATUS].p, c.dev[STATUS].p, 4, hipMemcpyDeviceToHost, st));
   SA_HIP_TRY(hipStreamSynchronize(st));
+  trace.mark("device done");
   const int status = *c.pin[STATUS].as<int>();
   if (status == SA_ERR_RANGE)
     return fail(SA_ERR_RANGE, "decimal Minimize: a k-mer value exceeds INT_MAX (stoi out of range)");
@@ -398,6 +403,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   const uint32_t* all = c.pin[OUT].as<uint32_t>();
   SA_HIP_TRY(hipMemcpyAsync(c.pin[OUT].p, c.dev[OUT].p, ooff[n] * 12, hipMemcpyDeviceToHost, st));
   SA_HIP_TRY(hipStreamSynchronize(st));
+  trace.mark("triples copied");
   std::atomic<bool> oom{false};
   parallel_for(n, 1024, threads, [&](size_t b0, size_t e0) {
     for (size_t j = b0; j < e0; ++j) {
@@ -413,6 +419,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
     }
   });
   if (oom) return fail(SA_ERR_ARGUMENT, "out of host memory");
+  trace.mark("lists handed out");
   return SA_OK;
 }
 

@@ -66,5 +66,41 @@ def main():
                           "pairs_per_s": round(n / best)}), flush=True)
 
 
+def minimizers():
+    """sa_minimize_batch_host: 20 000 reads of 10 kbp in one call, and one read per call."""
+    lib = capi.lib()
+    n, L = 20000, 10000
+    reads = np.ascontiguousarray(synth.reads(n, L, seed=8))
+    sp = (C.c_char_p * n)(*[C.c_char_p(reads.ctypes.data + i * L) for i in range(n)])
+    sl = (C.c_uint32 * n)(*([L] * n))
+    outs = (C.c_void_p * n)()
+    counts = (C.c_uint64 * n)()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        capi.check(lib.sa_minimize_batch_host(sp, sl, n, 15, 5, capi.SA_MIN_BINARY, 1, outs, counts))
+        best = min(best, time.perf_counter() - t0)
+        for i in range(n):
+            lib.sa_free(outs[i])
+    print(json.dumps({"case": "sa_minimize_batch_host 20000 x 10 kbp", "seconds": round(best, 4),
+                      "Gbases_per_s": round(n * L / best / 1e9, 2)}), flush=True)
+    one_s, one_l = (C.c_char_p * 1)(sp[0]), (C.c_uint32 * 1)(L)
+    for _ in range(10):
+        capi.check(lib.sa_minimize_batch_host(one_s, one_l, 1, 15, 5, capi.SA_MIN_BINARY, 1, outs, counts))
+        lib.sa_free(outs[0])
+    calls = 300
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        capi.check(lib.sa_minimize_batch_host(one_s, one_l, 1, 15, 5, capi.SA_MIN_BINARY, 1, outs, counts))
+        lib.sa_free(outs[0])
+    dt = time.perf_counter() - t0
+    print(json.dumps({"case": "one 10 kbp read per call (MinimizeBinary)", "calls": calls,
+                      "us_per_call": round(dt / calls * 1e6, 1)}), flush=True)
+
+
 if __name__ == "__main__":
+    if "--minimizers" in sys.argv:
+        sys.argv.remove("--minimizers")
+        minimizers()
+        sys.exit(0)
     main()
