@@ -2,8 +2,10 @@
 // drop-in library through the reference's own C++ prototypes, with plain checks instead of googletest,
 // plus the CIGAR / target_begin values the compiled reference produces for the same calls.
 #include <cstdio>
+#include <atomic>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -78,6 +80,48 @@ int main() {
     CHECK(u == uniq);
   }
   CHECK(CompressCigar("MMXDDI") == "1I2D1X2M");
+  {
+    // The mapper calls Align and MinimizeBinary from the threads of its pool (reference
+    // src/mapper.cpp:662-679 -> :410, :423): the same calls from 8 threads at once must give the answers
+    // of the single-threaded calls.
+    std::vector<std::string> reads;
+    unsigned x = 12345;
+    for (int i = 0; i < 8; ++i) {
+      std::string r;
+      for (int j = 0; j < 600 + 150 * i; ++j) {
+        x = x * 1664525u + 1013904223u;
+        r.push_back("ACGT"[(x >> 24) & 3]);
+      }
+      reads.push_back(r);
+    }
+    std::vector<int> score(8);
+    std::vector<std::string> cig(8);
+    std::vector<std::vector<Tuple>> mins(8);
+    for (int i = 0; i < 8; ++i) {
+      const std::string& q = reads[i];
+      const std::string& t = reads[(i + 1) % 8];
+      unsigned tb = 0;
+      score[i] = Align(q.c_str(), q.size(), t.c_str(), t.size(), (AlignmentType)(i % 3), 1, -1, -1, &cig[i], &tb);
+      mins[i] = MinimizeBinary(q.c_str(), q.size(), 15, 5);
+    }
+    std::atomic<int> bad{0};
+    std::vector<std::thread> pool;
+    for (int i = 0; i < 8; ++i)
+      pool.emplace_back([&, i]() {
+        const std::string& q = reads[i];
+        const std::string& t = reads[(i + 1) % 8];
+        for (int rep = 0; rep < 5; ++rep) {
+          std::string c;
+          unsigned tb = 0;
+          if (Align(q.c_str(), q.size(), t.c_str(), t.size(), (AlignmentType)(i % 3), 1, -1, -1, &c, &tb) != score[i] ||
+              c != cig[i])
+            ++bad;
+          if (MinimizeBinary(q.c_str(), q.size(), 15, 5) != mins[i]) ++bad;
+        }
+      });
+    for (auto& th : pool) th.join();
+    CHECK(bad == 0);
+  }
   std::printf(failures ? "%d check(s) failed\n" : "all drop-in checks passed\n", failures);
   return failures ? 1 : 0;
 }
