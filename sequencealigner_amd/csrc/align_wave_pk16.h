@@ -109,6 +109,11 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing stays pending into the step loop
       const uint32_t steps = T + 63;
       uint2* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
+      uint32_t pick_mask[C];  // wave-uniform: which half of which column holds a pair's last column
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+        pick_mask[k] = __builtin_amdgcn_readfirstlane(((uint32_t)k == regA ? 0x0000FFFFu : 0u) |
+                                                      ((uint32_t)k == regB ? 0xFFFF0000u : 0u));
       auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const uint32_t j = (st - 1) & 63;
@@ -157,13 +162,13 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
           drow[(uint64_t)st * 64] = make_uint2(acc0, acc1);
           ldiag = recv;
           lastcol = left;
-          if (s == stripA || s == stripB) {  // a pair's last column is in this strip
-            uint32_t pickA = 0, pickB = 0;
+          // a pair's last column is in this strip; Global wants it on one step only, the pair's last row
+          if ((s == stripA || s == stripB) &&
+              (MODE != SA_GLOBAL || (s == stripA && st == TA + laneA) || (s == stripB && st == TB + laneB))) {
+            uint32_t pick = 0;  // low half: pair A's column regA, high half: pair B's column regB
 #pragma unroll
-            for (int k = 0; k < C; ++k) {
-              pickA |= Hg[k] & ((uint32_t)k == regA ? 0x0000FFFFu : 0u);
-              pickB |= Hg[k] & ((uint32_t)k == regB ? 0xFFFF0000u : 0u);
-            }
+            for (int k = 0; k < C; ++k) pick = and_or(Hg[k], pick_mask[k], pick);
+            const uint32_t pickA = pick, pickB = pick;
             if (s == stripA && lane == laneA && i <= TA) {
               const int v = (int)(pickA & 0x7FFFu) - (int)bias - gap;
               if (MODE == SA_SEMIGLOBAL && v > bestA) {  // src/alignment.cpp:87-92, rows in increasing order
