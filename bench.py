@@ -176,7 +176,7 @@ def main():
     cells_per_launch = cells_rank * args.steps / fill_launches
     fill_cups = cells_per_launch / (fill_ms * 1e-3)
     achieved_tops = fill_cups * OPS_PER_CELL[typ] / 1e12
-    peak_tops = PEAK_PK16_TOPS if batch.kernel_name() == "lane_pk16" else PEAK_I32_TOPS
+    peak_tops = PEAK_PK16_TOPS if "pk16" in batch.kernel_name() else PEAK_I32_TOPS
     roofline = {
         "kernel": batch.kernel_name(), "bound": "valu_int", "achieved": achieved_tops,
         "peak": peak_tops, "unit": "Tops/s (integer lane-ops; %d per cell update)" % OPS_PER_CELL[typ],
@@ -229,7 +229,7 @@ def main():
                        "pairs_per_gpu": n, "cells_per_step_per_gpu": cells_rank},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        out["dtype"] = "u16x2" if batch.kernel_name() == "lane_pk16" else "int32"
+        out["dtype"] = "u16x2" if "pk16" in batch.kernel_name() else "int32"
         if not args.no_minimizers and not world.is_dist:
             del batch
             torch.cuda.empty_cache()
