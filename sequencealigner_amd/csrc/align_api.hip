@@ -152,9 +152,12 @@ Plan make_plan(const sa_align_batch& b) {
     const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
     const char* force_coop = getenv("SA_FORCE_COOP");
     pl.coop = b.n * strips8 <= 2048 && (force_coop ? atoi(force_coop) != 0 : (b.n <= 256 && max_q > 1024));
-    pl.wave_c = pl.coop ? coop_c : 16;
+    // A small batch of short queries is bound by the time of one step, not by throughput: 4 or 8 columns
+    // per lane instead of 16 put more lanes of the wavefront to work and shorten the step.
+    const bool narrow = !pl.coop && max_q <= 512 && b.n <= 4096;
+    pl.wave_c = pl.coop ? coop_c : narrow ? (max_q <= 256 ? 4 : 8) : 16;
     uint32_t wbias = 0;
-    pl.wave_pk = !pl.coop && !force_i32 && wave_pk16_applicable(b, &wbias);
+    pl.wave_pk = !pl.coop && !narrow && !force_i32 && wave_pk16_applicable(b, &wbias);
     const uint32_t strip = 64 * pl.wave_c;
     pl.family = Family::WaveI32;
     pl.name = pl.coop ? "wave_i32_coop" : pl.wave_pk ? "wave_pk16" : "wave_i32";
@@ -370,9 +373,11 @@ int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE>(pl, a, stream, need_tb);
   if (pl.family == Family::WaveI32)
-    return !pl.coop          ? launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb)
-           : pl.wave_c == 4 ? launch_wave_i32<MODE, 4, true>(a, co, stream, need_tb)
-                            : launch_wave_i32<MODE, 8, true>(a, co, stream, need_tb);
+    return pl.coop ? (pl.wave_c == 4 ? launch_wave_i32<MODE, 4, true>(a, co, stream, need_tb)
+                                     : launch_wave_i32<MODE, 8, true>(a, co, stream, need_tb))
+           : pl.wave_c == 4 ? launch_wave_i32<MODE, 4, false>(a, co, stream, need_tb)
+           : pl.wave_c == 8 ? launch_wave_i32<MODE, 8, false>(a, co, stream, need_tb)
+                            : launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb);
   switch (pl.K) {
     case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, alpha, stream, need_tb);
     case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb);
