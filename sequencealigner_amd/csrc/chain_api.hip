@@ -62,8 +62,42 @@ __global__ void ref_occurrences(uint32_t n, const uint32_t* id, const uint32_t* 
   keys[r] = r < m ? ((uint64_t)(run_start[r + 1] - run_start[r]) << 32) | run_value[r] : ~0ull;
 }
 
-__device__ __forceinline__ uint32_t find_run(const uint32_t* run_value, uint32_t m, uint32_t value) {
-  uint32_t lo = 0, hi = m;  // first run with value >= `value`
+// Lookup of a value among the m distinct reference values: a table over the values' top bits narrows the
+// binary search to the few runs that share them.  bucket[b] = first run whose value >> shift is >= b;
+// shift is chosen so that the largest value falls into the last of the kBuckets buckets.
+constexpr uint32_t kBucketBits = 18, kBuckets = 1u << kBucketBits;
+
+__device__ __forceinline__ uint32_t bucket_shift(uint32_t largest) {
+  const uint32_t bits = 32 - __builtin_clz(largest | 1u);
+  return bits > kBucketBits ? bits - kBucketBits : 0;
+}
+
+__global__ void ref_buckets(uint32_t n, const uint32_t* id, const uint32_t* run_value, uint32_t* bucket) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > kBuckets) return;
+  const uint32_t m = id[n];
+  const uint32_t shift = bucket_shift(run_value[m - 1]);
+  uint32_t lo = 0, hi = m;  // first run whose value is >= b << shift
+  if (b == kBuckets) {
+    lo = m;
+  } else {
+    const uint32_t least = b << shift;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (run_value[mid] < least)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+  }
+  bucket[b] = lo;
+}
+
+__device__ __forceinline__ uint32_t find_run(const uint32_t* run_value, const uint32_t* bucket, uint32_t m,
+                                             uint32_t value) {
+  const uint32_t b = value >> bucket_shift(run_value[m - 1]);
+  if (b >= kBuckets) return ~0u;  // above the largest reference value
+  uint32_t lo = bucket[b], hi = bucket[b + 1];  // first run with value >= `value` lies in [lo, hi]
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
     if (run_value[mid] < value)
@@ -76,13 +110,13 @@ __device__ __forceinline__ uint32_t find_run(const uint32_t* run_value, uint32_t
 
 // the last (int)((int)m * f) keys of the sorted list are the values to drop (src/mapper.cpp:226-231)
 __global__ void ref_drop(uint32_t n, const uint32_t* id, const uint64_t* sorted, const uint32_t* run_value,
-                         float f, uint8_t* alive) {
+                         const uint32_t* bucket, float f, uint8_t* alive) {
   const uint32_t m = id[n];
   const int index = (int)((float)(int)m * f);
   const int from = (int)m - index;
   const int x = from + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (x < 0 || x >= (int)m) return;
-  const uint32_t r = find_run(run_value, m, (uint32_t)sorted[x]);
+  const uint32_t r = find_run(run_value, bucket, m, (uint32_t)sorted[x]);
   if (r != ~0u) alive[r] = 0;
 }
 
@@ -93,6 +127,7 @@ struct ChainArgs {
   const uint32_t* id;          // id[n_ref] = number of runs
   const uint32_t* run_start;
   const uint32_t* run_value;
+  const uint32_t* bucket;      // lookup table over the values' top bits (find_run)
   const uint32_t* strand_pre;  // exclusive prefix of the reference strand flags
   const uint8_t* alive;
   const uint32_t* reads;
@@ -108,7 +143,7 @@ __global__ void match_count(ChainArgs a, uint32_t* cnt) {
   uint32_t c = 0;
   if (x < a.n_read_triples) {
     const uint32_t m = a.id[a.n_ref];
-    const uint32_t r = find_run(a.run_value, m, a.reads[3 * x]);
+    const uint32_t r = find_run(a.run_value, a.bucket, m, a.reads[3 * x]);
     if (r != ~0u && a.alive[r]) {
       const uint32_t b = a.run_start[r], e = a.run_start[r + 1];
       const uint32_t ones = a.strand_pre[e] - a.strand_pre[b];
@@ -123,7 +158,7 @@ __global__ void match_write(ChainArgs a, const uint64_t* moff, uint64_t* keys) {
   const uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (x >= a.n_read_triples || moff[x + 1] == moff[x]) return;
   const uint32_t m = a.id[a.n_ref];
-  const uint32_t r = find_run(a.run_value, m, a.reads[3 * x]);
+  const uint32_t r = find_run(a.run_value, a.bucket, m, a.reads[3 * x]);
   const uint32_t strand = a.reads[3 * x + 2] ? 1u : 0u;
   const uint64_t qpos = (uint64_t)a.reads[3 * x + 1] << 32;
   uint64_t o = moff[x];
@@ -203,7 +238,7 @@ __global__ void chain_lis(const uint64_t* sorted, const uint32_t* seg_begin, con
 }
 
 struct ChainPlan {
-  size_t o_head, o_strand, o_id, o_strand_pre, o_run_start, o_run_value, o_okeys, o_osorted, o_alive, o_cnt,
+  size_t o_head, o_strand, o_id, o_strand_pre, o_run_start, o_run_value, o_bucket, o_okeys, o_osorted, o_alive, o_cnt,
       o_moff, o_seg_begin, o_seg_end, o_tmp_fixed, fixed_bytes;
   size_t scan_ref_tmp, scan_read_tmp, sort_ref_tmp;
 };
@@ -228,6 +263,7 @@ int make_chain_plan(uint32_t n_ref, uint64_t n_read_triples, uint32_t n_reads, C
   pl->o_strand_pre = take(r1 * 4);
   pl->o_run_start = take(r1 * 4);
   pl->o_run_value = take(r1 * 4);
+  pl->o_bucket = take(((size_t)kBuckets + 2) * 4);
   pl->o_okeys = take(r1 * 8);
   pl->o_osorted = take(r1 * 8);
   pl->o_alive = take(r1);
@@ -269,6 +305,7 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
   uint32_t* strand_pre = (uint32_t*)(ws + pl.o_strand_pre);
   uint32_t* run_start = (uint32_t*)(ws + pl.o_run_start);
   uint32_t* run_value = (uint32_t*)(ws + pl.o_run_value);
+  uint32_t* bucket = (uint32_t*)(ws + pl.o_bucket);
   uint64_t* okeys = (uint64_t*)(ws + pl.o_okeys);
   uint64_t* osorted = (uint64_t*)(ws + pl.o_osorted);
   uint8_t* alive = (uint8_t*)(ws + pl.o_alive);
@@ -289,17 +326,18 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
                                      stream));
   hipLaunchKernelGGL(ref_runs, blocks((uint64_t)n + 1), dim3(kThreads), 0, stream, b->d_ref, n, head, id,
                      run_start, run_value);
+  hipLaunchKernelGGL(ref_buckets, blocks((uint64_t)kBuckets + 1), dim3(kThreads), 0, stream, n, id, run_value, bucket);
   hipLaunchKernelGGL(ref_occurrences, blocks(n), dim3(kThreads), 0, stream, n, id, run_start, run_value, okeys,
                      alive);
   SA_HIP_TRY(hipGetLastError());
   t = pl.sort_ref_tmp;
   SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, okeys, osorted, (size_t)n, 0u, 64u, stream));
-  hipLaunchKernelGGL(ref_drop, blocks(n), dim3(kThreads), 0, stream, n, id, osorted, run_value,
+  hipLaunchKernelGGL(ref_drop, blocks(n), dim3(kThreads), 0, stream, n, id, osorted, run_value, bucket,
                      b->frequent_fraction, alive);
   SA_HIP_TRY(hipGetLastError());
 
   // matches: count, offsets, total
-  ChainArgs a{b->d_ref, n, id, run_start, run_value, strand_pre, alive, b->d_reads, b->d_read_off, b->n_reads,
+  ChainArgs a{b->d_ref, n, id, run_start, run_value, bucket, strand_pre, alive, b->d_reads, b->d_read_off, b->n_reads,
               b->n_read_triples};
   hipLaunchKernelGGL(match_count, blocks(b->n_read_triples + 1), dim3(kThreads), 0, stream, a, cnt);
   SA_HIP_TRY(hipGetLastError());
