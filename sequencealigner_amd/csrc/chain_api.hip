@@ -176,60 +176,70 @@ __global__ void read_segments(const uint64_t* read_off, uint32_t n_reads, const 
   if (n_matches) n_matches[r] = e - b;
 }
 
-// ---- longest increasing subsequence, one thread per read (src/mapper.cpp:292-352) -----------------------
-// tails[len] = index of the match that ends the best subsequence of that length (tailv[len] = its
-// reference position, so that a search step is one load), parent[i] = its predecessor; the read's slices
-// start at seg_begin[r] (+ r for tails / tailv: n + 1 entries).  A match beyond the current best end is
-// appended without a search - the search would end there too.
-__global__ void chain_lis(const uint64_t* sorted, const uint32_t* seg_begin, const uint32_t* seg_end,
-                          uint32_t n_reads, int32_t* parent_all, int32_t* tails_all, uint32_t* tailv_all,
-                          int32_t* out) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- longest increasing subsequence, one wavefront per read (src/mapper.cpp:292-352) --------------------
+// The reference keeps, per length, the match that ends the best subsequence of that length (tails) and a
+// predecessor per match, and walks the predecessors back from the longest one to find where it starts.
+// Here tails[len] / tailv[len] hold that match and its reference position (a search step is one load) and
+// root[i] the FIRST match of the best subsequence that ends in match i, which is all the walk back is for:
+// root[i] = i when i starts a subsequence, else root of its predecessor.  A match beyond the current best
+// end is appended without a search - the search would end there too - and then its predecessor and root are
+// already in registers.  The wave fetches 64 matches at a time; every lane runs the same sequential code.
+// The read's slices start at seg_begin[r] (+ r for tails / tailv: n + 1 entries).
+__global__ __launch_bounds__(kThreads) void chain_lis(const uint64_t* sorted, const uint32_t* seg_begin,
+                                                      const uint32_t* seg_end, uint32_t n_reads,
+                                                      int32_t* root_all, int32_t* tails_all, uint32_t* tailv_all,
+                                                      int32_t* out) {
+  const uint32_t r = (blockIdx.x * kThreads + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
   if (r >= n_reads) return;
   const uint64_t* mt = sorted + seg_begin[r];
   const int n = (int)(seg_end[r] - seg_begin[r]);
   int32_t* o = out + 5 * (uint64_t)r;
   if (n == 0) {
-    o[0] = o[1] = o[2] = o[3] = o[4] = 0;
+    if (lane < 5) o[lane] = 0;
     return;
   }
-  if (n == 1) {
-    o[0] = 1;
-    o[1] = o[2] = (int32_t)(uint32_t)mt[0];
-    o[3] = o[4] = (int32_t)(mt[0] >> 32);
-    return;
-  }
-  int32_t* parent = parent_all + seg_begin[r];
+  int32_t* root = root_all + seg_begin[r];
   int32_t* tails = tails_all + seg_begin[r] + r;
   uint32_t* tailv = tailv_all + seg_begin[r] + r;
-  const int32_t INF = 1000000000;
-  tails[0] = INF;
   int length = 0;
-  uint32_t best_end = 0;  // tailv[length]
-  for (int i = 0; i < n; ++i) {
-    const uint32_t ref_i = (uint32_t)mt[i];
-    int low = length + 1;
-    if (length != 0 && !(best_end < ref_i)) {
-      low = 1;
-      int high = length;
-      while (low <= high) {
-        const int mid = (low + high) / 2;
-        if (tailv[mid] < ref_i)
-          low = mid + 1;
-        else
-          high = mid - 1;
+  uint32_t best_end = 0;        // tailv[length]
+  int top = 0, root_top = 0;    // tails[length] and its root
+  for (int base = 0; base < n; base += 64) {
+    const uint64_t mine = base + (int)lane < n ? mt[base + lane] : 0;
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int j = 0; j < cnt; ++j) {
+      const int i = base + j;
+      const uint32_t ref_i = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
+      int low, root_i;
+      if (length == 0 || best_end < ref_i) {
+        low = length + 1;
+        root_i = length == 0 ? i : root_top;
+      } else {
+        low = 1;
+        int high = length;
+        while (low <= high) {
+          const int mid = (low + high) / 2;
+          if (tailv[mid] < ref_i)
+            low = mid + 1;
+          else
+            high = mid - 1;
+        }
+        root_i = low == 1 ? i : root[tails[low - 1]];
+      }
+      // every lane stores the same values to the same places
+      root[i] = root_i;
+      tails[low] = i;
+      tailv[low] = ref_i;
+      if (low > length) length = low;
+      if (low == length) {
+        best_end = ref_i;
+        top = i;
+        root_top = root_i;
       }
     }
-    parent[i] = tails[low - 1];
-    tails[low] = i;
-    tailv[low] = ref_i;
-    if (low > length) length = low;
-    if (low == length) best_end = ref_i;
   }
-  int k = tails[length];
-  const uint64_t last = mt[k];
-  for (int j = length - 1; j > 0; --j) k = parent[k];
-  const uint64_t first = mt[k];
+  if (lane != 0) return;
+  const uint64_t last = mt[top], first = mt[root_top];
   o[0] = length;
   o[1] = (int32_t)(uint32_t)first;
   o[2] = (int32_t)(uint32_t)last;
@@ -380,7 +390,7 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
     SA_HIP_TRY(rocprim::segmented_radix_sort_keys(ws + o_sort_tmp, t, keys, sorted, (unsigned)total, b->n_reads,
                                                   seg_begin, seg_end, 0u, 64u, stream));
   }
-  hipLaunchKernelGGL(chain_lis, blocks(b->n_reads), dim3(kThreads), 0, stream, sorted, seg_begin, seg_end,
+  hipLaunchKernelGGL(chain_lis, blocks((uint64_t)b->n_reads * 64), dim3(kThreads), 0, stream, sorted, seg_begin, seg_end,
                      b->n_reads, (int32_t*)(ws + o_parent), (int32_t*)(ws + o_tails), (uint32_t*)(ws + o_tailv),
                      b->d_out);
   SA_HIP_TRY(hipGetLastError());
