@@ -28,7 +28,7 @@ def chain_batch(d_ref, d_reads, d_read_off, frequent_fraction=0.0, device=None, 
     stream = torch.cuda.current_stream(dev)
     need = C.c_size_t(0)
     # a first guess that usually holds every match (the library says how much it needs when it does not)
-    ws = torch.empty((1 << 20) + 64 * int(d_ref.shape[0]) + 48 * total, dtype=torch.uint8, device=dev)
+    ws = torch.empty((4 << 20) + 64 * int(d_ref.shape[0]) + 48 * total, dtype=torch.uint8, device=dev)
     for _ in range(3):  # the number of matches sizes the workspace: grow it as the library asks
         rc = lib.sa_chain_batch_device(dev.index or 0, stream.cuda_stream, C.byref(b), ws.data_ptr(), ws.numel(),
                                        C.byref(need))

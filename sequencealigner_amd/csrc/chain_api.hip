@@ -120,6 +120,16 @@ __global__ void ref_drop(uint32_t n, const uint32_t* id, const uint64_t* sorted,
   if (r != ~0u) alive[r] = 0;
 }
 
+// What a lookup needs of a run once the frequency filter is final, in one 16-byte entry: first triple,
+// number of triples, number of those on the forward strand, alive.
+__global__ void ref_info(uint32_t n, const uint32_t* id, const uint32_t* run_start, const uint32_t* strand_pre,
+                         const uint8_t* alive, uint4* info) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= id[n]) return;
+  const uint32_t b = run_start[r], e = run_start[r + 1];
+  info[r] = make_uint4(b, e - b, strand_pre[e] - strand_pre[b], alive[r]);
+}
+
 // ---- matches -------------------------------------------------------------------------------------------
 struct ChainArgs {
   const uint32_t* ref;
@@ -130,6 +140,8 @@ struct ChainArgs {
   const uint32_t* bucket;      // lookup table over the values' top bits (find_run)
   const uint32_t* strand_pre;  // exclusive prefix of the reference strand flags
   const uint8_t* alive;
+  const uint4* info;           // per run: first triple, triples, forward-strand triples, alive
+  uint32_t* rid;               // per read triple: its run (or ~0), kept from the counting pass for the writing pass
   const uint32_t* reads;
   const uint64_t* read_off;
   uint32_t n_reads;
@@ -143,12 +155,15 @@ __global__ void match_count(ChainArgs a, uint32_t* cnt) {
   uint32_t c = 0;
   if (x < a.n_read_triples) {
     const uint32_t m = a.id[a.n_ref];
-    const uint32_t r = find_run(a.run_value, a.bucket, m, a.reads[3 * x]);
-    if (r != ~0u && a.alive[r]) {
-      const uint32_t b = a.run_start[r], e = a.run_start[r + 1];
-      const uint32_t ones = a.strand_pre[e] - a.strand_pre[b];
-      c = a.reads[3 * x + 2] ? ones : (e - b) - ones;
+    uint32_t r = find_run(a.run_value, a.bucket, m, a.reads[3 * x]);
+    if (r != ~0u) {
+      const uint4 run = a.info[r];
+      if (run.w)
+        c = a.reads[3 * x + 2] ? run.z : run.y - run.z;
+      else
+        r = ~0u;
     }
+    a.rid[x] = r;
   }
   cnt[x] = c;
 }
@@ -157,12 +172,11 @@ __global__ void match_count(ChainArgs a, uint32_t* cnt) {
 __global__ void match_write(ChainArgs a, const uint64_t* moff, uint64_t* keys) {
   const uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (x >= a.n_read_triples || moff[x + 1] == moff[x]) return;
-  const uint32_t m = a.id[a.n_ref];
-  const uint32_t r = find_run(a.run_value, a.bucket, m, a.reads[3 * x]);
+  const uint4 run = a.info[a.rid[x]];
   const uint32_t strand = a.reads[3 * x + 2] ? 1u : 0u;
   const uint64_t qpos = (uint64_t)a.reads[3 * x + 1] << 32;
   uint64_t o = moff[x];
-  for (uint32_t y = a.run_start[r]; y < a.run_start[r + 1]; ++y)
+  for (uint32_t y = run.x; y < run.x + run.y; ++y)
     if ((a.ref[3 * y + 2] ? 1u : 0u) == strand) keys[o++] = qpos | a.ref[3 * y + 1];
 }
 
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void chain_lis(const uint64_t* sorted, co
 }
 
 struct ChainPlan {
-  size_t o_head, o_strand, o_id, o_strand_pre, o_run_start, o_run_value, o_bucket, o_okeys, o_osorted, o_alive, o_cnt,
+  size_t o_head, o_strand, o_id, o_strand_pre, o_run_start, o_run_value, o_bucket, o_info, o_rid, o_okeys, o_osorted, o_alive, o_cnt,
       o_moff, o_seg_begin, o_seg_end, o_tmp_fixed, fixed_bytes;
   size_t scan_ref_tmp, scan_read_tmp, sort_ref_tmp;
 };
@@ -274,6 +288,8 @@ int make_chain_plan(uint32_t n_ref, uint64_t n_read_triples, uint32_t n_reads, C
   pl->o_run_start = take(r1 * 4);
   pl->o_run_value = take(r1 * 4);
   pl->o_bucket = take(((size_t)kBuckets + 2) * 4);
+  pl->o_info = take(r1 * 16);
+  pl->o_rid = take((n_read_triples + 1) * 4);
   pl->o_okeys = take(r1 * 8);
   pl->o_osorted = take(r1 * 8);
   pl->o_alive = take(r1);
@@ -316,6 +332,8 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
   uint32_t* run_start = (uint32_t*)(ws + pl.o_run_start);
   uint32_t* run_value = (uint32_t*)(ws + pl.o_run_value);
   uint32_t* bucket = (uint32_t*)(ws + pl.o_bucket);
+  uint4* info = (uint4*)(ws + pl.o_info);
+  uint32_t* rid = (uint32_t*)(ws + pl.o_rid);
   uint64_t* okeys = (uint64_t*)(ws + pl.o_okeys);
   uint64_t* osorted = (uint64_t*)(ws + pl.o_osorted);
   uint8_t* alive = (uint8_t*)(ws + pl.o_alive);
@@ -344,10 +362,11 @@ extern "C" int sa_chain_batch_device(int device, void* stream_, const sa_chain_b
   SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, okeys, osorted, (size_t)n, 0u, 64u, stream));
   hipLaunchKernelGGL(ref_drop, blocks(n), dim3(kThreads), 0, stream, n, id, osorted, run_value, bucket,
                      b->frequent_fraction, alive);
+  hipLaunchKernelGGL(ref_info, blocks(n), dim3(kThreads), 0, stream, n, id, run_start, strand_pre, alive, info);
   SA_HIP_TRY(hipGetLastError());
 
   // matches: count, offsets, total
-  ChainArgs a{b->d_ref, n, id, run_start, run_value, bucket, strand_pre, alive, b->d_reads, b->d_read_off, b->n_reads,
+  ChainArgs a{b->d_ref, n, id, run_start, run_value, bucket, strand_pre, alive, info, rid, b->d_reads, b->d_read_off, b->n_reads,
               b->n_read_triples};
   hipLaunchKernelGGL(match_count, blocks(b->n_read_triples + 1), dim3(kThreads), 0, stream, a, cnt);
   SA_HIP_TRY(hipGetLastError());
