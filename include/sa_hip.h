@@ -70,6 +70,9 @@ const char* sa_device_arch(int device);
  * batches of few long pairs, which run cooperatively (kernel name "wave_i32_coop") and synchronise the
  * stream once at the end to read the kernels' abort flag.
  *
+ * The batch is planned for max_qlen x max_tlen: every pair pays for direction words and steps of that shape.
+ * Callers with mixed sizes should issue one call per size class (sa_align_batch_host does).
+ *
  * Outputs (each may be NULL if not wanted, except d_score):
  *   d_score[p]         alignment score
  *   d_target_begin[p]  the value the reference stores in *target_begin (src/alignment.cpp:129-136,
@@ -136,7 +139,8 @@ int sa_cigar_stats_device(int device, void* stream, uint32_t n, const uint32_t* 
 /* ---------------------------------------------------------------------------------------------
  * Alignment, host buffers.  The device batch queue: pairs are split over `n_devices` GPUs
  * (0 = all visible) by cost (query_len * target_len), staged through pinned buffers, aligned on each
- * GPU's own stream and gathered back in input order - no inter-GPU communication.
+ * GPU's own stream and gathered back in input order - no inter-GPU communication.  Pairs are grouped by
+ * size class (powers of two of query and target length) and each class runs as a batch of its own.
  * cigars (optional) receives n malloc'ed NUL-terminated CIGAR strings, "<count><op>..." exactly as
  * CompressCigar prints them (src/alignment.cpp:17-33); free each with sa_free().
  * ------------------------------------------------------------------------------------------- */

@@ -161,6 +161,24 @@ class DeviceAlignBatch:
         return out
 
 
+def size_classes(qlens, tlens, few=64):
+    """Groups pair indices by size class (powers of two of query and target length, at least 64): a device
+    batch is planned for its longest query and target, so a few long outliers among many short pairs would
+    make every pair pay for their matrix.  Classes of fewer than `few` pairs are put together into one batch,
+    the last of the list: so few pairs run on kernels that give every pair its own wavefronts and its own
+    number of steps, and are best started on a stream of their own beside the large classes.
+    -> (list of index arrays, largest class first; True if the last one is that collection)."""
+    qlens, tlens = np.asarray(qlens, dtype=np.int64), np.asarray(tlens, dtype=np.int64)
+    key = (np.ceil(np.log2(np.maximum(tlens, 64))).astype(np.int64) << 8) | \
+        np.ceil(np.log2(np.maximum(qlens, 64))).astype(np.int64)
+    groups = [np.nonzero(key == k)[0] for k in sorted(set(key.tolist()), reverse=True)]
+    large = [g for g in groups if g.size >= few]
+    small = [g for g in groups if g.size < few]
+    if small and large:
+        return large + [np.sort(np.concatenate(small))], True
+    return groups, False
+
+
 def align_batch(queries, targets, type_, match, mismatch, gap, want_cigar=True, device=0):
     """-> (scores int32[n], cigars list[str] or None, target_begin uint32[n])"""
     b = DeviceAlignBatch(queries, targets, type_, match, mismatch, gap, want_cigar, True, device)

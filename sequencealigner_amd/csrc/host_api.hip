@@ -503,27 +503,75 @@ int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
   if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many pairs");
   const int ndev = pick_devices(n_devices);
   if (ndev == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
-  std::vector<uint64_t> cost(n);
-  for (size_t i = 0; i < n; ++i)
-    cost[i] = ((uint64_t)target_lens[i] << 32) | query_lens[i];  // order by target, then query length
-  auto shards = deal(cost, ndev, 1024);
-  // Large shards are cut into parts that run as independent calls on streams of their own: one part's
-  // copies overlap another part's kernels, and staging and CIGAR text of the parts proceed in parallel.
-  size_t largest = 0;
-  for (const auto& sh : shards) largest = std::max(largest, sh.size());
-  const unsigned parts = largest >= 262144 ? 4 : largest >= 65536 ? 2 : 1;
-  if (parts > 1) {
-    std::vector<std::vector<uint32_t>> cut;
-    for (const auto& sh : shards)
-      for (unsigned p = 0; p < parts; ++p)
-        cut.emplace_back(sh.begin() + sh.size() * p / parts, sh.begin() + sh.size() * (p + 1) / parts);
-    shards.swap(cut);
+  // A device batch is planned for its longest query and target: pairs are grouped by size class (powers of
+  // two of both lengths, at least 64) and every class is run as a batch of its own, so that a few long
+  // outliers do not make every pair pay for their matrix.  Classes of fewer than 64 pairs run together.
+  auto log2_ceil = [](uint32_t v) {
+    uint32_t b = 6;
+    while (b < 32 && (1ull << b) < v) ++b;
+    return b;
+  };
+  auto class_of = [&](size_t i) { return (log2_ceil(target_lens[i]) << 8) | log2_ceil(query_lens[i]); };
+  std::vector<std::vector<uint32_t>> classes;
+  {
+    // the common case first: every pair in the class of pair 0 (two range tests per pair)
+    const uint32_t bq = log2_ceil(query_lens[0]), bt = log2_ceil(target_lens[0]);
+    const uint64_t q_hi = 1ull << bq, q_lo = bq == 6 ? 0 : 1ull << (bq - 1);
+    const uint64_t t_hi = 1ull << bt, t_lo = bt == 6 ? 0 : 1ull << (bt - 1);
+    size_t i = 0;
+    for (; i < n; ++i) {
+      const uint64_t q = query_lens[i], t = target_lens[i];
+      if (q > q_hi || (q <= q_lo && q_lo) || t > t_hi || (t <= t_lo && t_lo)) break;
+    }
+    if (i == n) {
+      classes.emplace_back(n);
+      std::iota(classes[0].begin(), classes[0].end(), 0u);
+    }
   }
-  const unsigned threads = std::max(1u, host_threads() / (unsigned)(ndev * parts));
-  return run_on_devices(ndev * parts, [&](int task) {
-    return align_shard(task / parts, shards[task], queries, query_lens, targets, target_lens, type, match,
-                       mismatch, gap, scores, target_begin, cigars, threads, parts);
-  });
+  const bool in_order = !classes.empty();  // one class that lists the pairs in their order
+  if (classes.empty()) {
+    std::vector<std::pair<uint32_t, uint32_t>> keyed(n);  // (class, pair)
+    for (size_t i = 0; i < n; ++i) keyed[i] = {class_of(i), (uint32_t)i};
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+    std::vector<uint32_t> rest;
+    for (size_t i = 0; i < n;) {
+      size_t e = i;
+      while (e < n && keyed[e].first == keyed[i].first) ++e;
+      std::vector<uint32_t>& into = e - i >= 64 ? classes.emplace_back() : rest;
+      for (size_t x = i; x < e; ++x) into.push_back(keyed[x].second);
+      i = e;
+    }
+    if (!rest.empty()) classes.push_back(std::move(rest));
+  }
+
+  for (const std::vector<uint32_t>& members : classes) {
+    std::vector<uint64_t> cost(members.size());
+    for (size_t i = 0; i < members.size(); ++i)  // order by target, then query length
+      cost[i] = ((uint64_t)target_lens[members[i]] << 32) | query_lens[members[i]];
+    auto shards = deal(cost, ndev, 1024);
+    if (!in_order)  // class members -> pair numbers
+      for (auto& sh : shards)
+        for (uint32_t& x : sh) x = members[x];
+    // Large shards are cut into parts that run as independent calls on streams of their own: one part's
+    // copies overlap another part's kernels, and staging and CIGAR text of the parts proceed in parallel.
+    size_t largest = 0;
+    for (const auto& sh : shards) largest = std::max(largest, sh.size());
+    const unsigned parts = largest >= 262144 ? 4 : largest >= 65536 ? 2 : 1;
+    if (parts > 1) {
+      std::vector<std::vector<uint32_t>> cut;
+      for (const auto& sh : shards)
+        for (unsigned p = 0; p < parts; ++p)
+          cut.emplace_back(sh.begin() + sh.size() * p / parts, sh.begin() + sh.size() * (p + 1) / parts);
+      shards.swap(cut);
+    }
+    const unsigned threads = std::max(1u, host_threads() / (unsigned)(ndev * parts));
+    const int rc = run_on_devices(ndev * parts, [&](int task) {
+      return align_shard(task / parts, shards[task], queries, query_lens, targets, target_lens, type, match,
+                         mismatch, gap, scores, target_begin, cigars, threads, parts);
+    });
+    if (rc) return rc;
+  }
+  return SA_OK;
 }
 
 int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t n, uint32_t k,

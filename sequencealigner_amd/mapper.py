@@ -20,6 +20,30 @@ def _device_lists(seqs, k, w, device):
     return b.d_out[:3 * n].clone().reshape(n, 3), off
 
 
+def _run_classes(idx, qlens, tlens, make_batch, cigars, block, device):
+    """Aligns the pairs `idx` as one batch per size class (a chained reference span may be anything up to
+    100 000 bases; one batch would be planned for the longest).  The few pairs of rare sizes form one batch
+    that runs on a stream of its own beside the others."""
+    if not idx.size:
+        return
+    classes, has_rest = align.size_classes(qlens, tlens)
+    batches = [(idx[cls], make_batch(idx[cls])) for cls in classes]
+    side = torch.cuda.Stream(device) if has_rest else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(device))  # the batches' inputs were made on the current stream
+    for n_cls, (_, batch) in enumerate(batches):
+        # the rare sizes last: their call waits for its kernels (cooperative kernel), the others only enqueue
+        if side is not None and n_cls == len(batches) - 1:
+            batch.run(side)
+        else:
+            batch.run()
+    torch.cuda.synchronize(device)
+    for sel, batch in batches:
+        bl, _ = batch.cigar_stats()
+        for j, (i, c) in enumerate(zip(sel, batch.cigars())):
+            cigars[i], block[i] = c, int(bl[j])
+
+
 def map_reads(ref_name, ref_seq, read_names, reads, k=15, w=5, f=0.001, match=1, mismatch=-1, gap=-1,
               cigar_needed=True, device=0):
     """Returns the PAF records (strings ending in a newline) in read order."""
@@ -34,14 +58,11 @@ def map_reads(ref_name, ref_seq, read_names, reads, k=15, w=5, f=0.001, match=1,
     to_align = (lis > 0) & ((te - tb) < 100000) & cigar_needed & (lens < 5000)
     idx = np.nonzero(to_align)[0]
     cigars, block = {}, {}
-    if idx.size:
-        batch = align.DeviceAlignBatch([reads[i][qb[i]:qe[i]] for i in idx], [ref_seq[tb[i]:te[i]] for i in idx],
-                                       align.AlignmentType.Global, match, mismatch, gap, device=device)
-        batch.run()
-        torch.cuda.synchronize(device)
-        bl, _ = batch.cigar_stats()
-        for j, (i, c) in enumerate(zip(idx, batch.cigars())):
-            cigars[i], block[i] = c, int(bl[j])
+    def make(sel):
+        return align.DeviceAlignBatch([reads[i][qb[i]:qe[i]] for i in sel], [ref_seq[tb[i]:te[i]] for i in sel],
+                                      align.AlignmentType.Global, match, mismatch, gap, device=device)
+
+    _run_classes(idx, qe[idx] - qb[idx], te[idx] - tb[idx], make, cigars, block, device)
     out = []
     for i in range(n):
         if to_align[i]:
@@ -86,16 +107,13 @@ def map_records(ref, ref_name, reads, read_names, k=15, w=5, f=0.001, match=1, m
     to_align = (lis > 0) & ((te - tb) < 100000) & cigar_needed & (lens < 5000)
     idx = np.nonzero(to_align)[0]
     cigars, block = {}, {}
-    if idx.size:
-        d_q, d_qo = ingest.gather_spans(reads.d_seq, read_off[idx] + qb[idx], qe[idx] - qb[idx], device)
-        d_t, d_to = ingest.gather_spans(ref.d_seq, tb[idx], te[idx] - tb[idx], device)
-        batch = align.DeviceAlignBatch.from_device(d_q, d_qo, d_t, d_to, qe[idx] - qb[idx], te[idx] - tb[idx],
-                                                   align.AlignmentType.Global, match, mismatch, gap, device=device)
-        batch.run()
-        torch.cuda.synchronize(device)
-        bl, _ = batch.cigar_stats()
-        for j, (i, c) in enumerate(zip(idx, batch.cigars())):
-            cigars[i], block[i] = c, int(bl[j])
+    def make(sel):
+        d_q, d_qo = ingest.gather_spans(reads.d_seq, read_off[sel] + qb[sel], qe[sel] - qb[sel], device)
+        d_t, d_to = ingest.gather_spans(ref.d_seq, tb[sel], te[sel] - tb[sel], device)
+        return align.DeviceAlignBatch.from_device(d_q, d_qo, d_t, d_to, qe[sel] - qb[sel], te[sel] - tb[sel],
+                                                  align.AlignmentType.Global, match, mismatch, gap, device=device)
+
+    _run_classes(idx, qe[idx] - qb[idx], te[idx] - tb[idx], make, cigars, block, device)
     short, long_ = ingest.split_fragments(lens)
     out = []
     for i in list(long_) + list(short):

@@ -107,3 +107,35 @@ def test_align_batch_host_large_batch_in_parts():
         if i % 7 == 0:
             assert C.cast(cig[i], C.c_char_p).value.decode() == want_c[i], i
         lib.sa_free(cig[i])
+
+
+def test_align_batch_host_with_outliers(oracle):
+    """Many short pairs and a few long, thin ones in one call: the entry point runs them as batches by size
+    class; results come back in input order."""
+    from sequencealigner_amd import capi, synth
+    lib = capi.lib()
+    rng = np.random.default_rng(21)
+    qs, ts = [], []
+    for i in range(400):
+        long_one = i in (7, 250, 399)
+        T = int(rng.integers(3000, 6000)) if long_one else int(rng.integers(100, 160))
+        t = bytes(synth.random_bases(rng, T))
+        a = int(rng.integers(0, T // 2))
+        q = bytes(synth.substitute(rng, np.frombuffer(t[a:a + int(rng.integers(60, 100))], np.uint8), 0.05))
+        qs.append(q)
+        ts.append(t)
+    n = len(qs)
+    for typ in (0, 2):
+        qa, ql = _c_strings(qs)
+        ta, tl = _c_strings(ts)
+        scores = (C.c_int32 * n)()
+        tb = (C.c_uint32 * n)()
+        cig = (C.c_void_p * n)()
+        capi.check(lib.sa_align_batch_host(qa, ql, ta, tl, n, typ, 1, -1, -1, 0, scores, tb, cig))
+        for i in range(n):
+            got_c = C.cast(cig[i], C.c_char_p).value.decode()
+            lib.sa_free(cig[i])
+            want = oracle.align(qs[i], ts[i], typ, 1, -1, -1)
+            if typ == 2 and want[0] <= 0:
+                continue
+            assert (scores[i], got_c, tb[i]) == want, (i, typ)
