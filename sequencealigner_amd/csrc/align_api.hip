@@ -144,11 +144,14 @@ Plan make_plan(const sa_align_batch& b) {
     want_wave = false;
   if (want_wave) {
     // Few long pairs: spread every pair's strips over as many wavefronts (narrow strips, all resident).
-    static const int coop_c = [] {  // SA_COOP_C=4|8: columns per lane of the cooperative kernel
+    // columns per lane of the cooperative kernel: 4 (more, shorter steps in flight) while all wavefronts of
+    // the batch stay resident, else 8; SA_COOP_C=4|8 pins it
+    static const int coop_env = [] {
       const char* e = getenv("SA_COOP_C");
-      const int v = e ? atoi(e) : 8;
-      return v == 4 ? 4 : 8;
+      const int v = e ? atoi(e) : 0;
+      return v == 4 || v == 8 ? v : 0;
     }();
+    const int coop_c = coop_env ? coop_env : ((uint64_t)b.n * ((max_q + 255) / 256) <= 2048 ? 4 : 8);
     const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
     const char* force_coop = getenv("SA_FORCE_COOP");
     pl.coop = b.n * strips8 <= 2048 && (force_coop ? atoi(force_coop) != 0 : (b.n <= 256 && max_q > 1024));
