@@ -50,7 +50,8 @@ enum {
   SA_ERR_NO_DEVICE = 4,    /* no usable GPU */
   SA_ERR_RANGE = 5,        /* decimal Minimize: k-mer value exceeds INT_MAX (reference throws from stoi) */
   SA_ERR_CAPACITY = 6,     /* an output buffer is too small */
-  SA_ERR_FORMAT = 7        /* a sequence file breaks the rules of its format */
+  SA_ERR_FORMAT = 7,       /* a sequence file breaks the rules of its format */
+  SA_ERR_MEMORY = 8        /* host memory exhausted */
 };
 
 const char* sa_last_error(void);
@@ -142,7 +143,8 @@ int sa_cigar_stats_device(int device, void* stream, uint32_t n, const uint32_t* 
  * GPU's own stream and gathered back in input order - no inter-GPU communication.  Pairs are grouped by
  * size class (powers of two of query and target length) and each class runs as a batch of its own.
  * cigars (optional) receives n malloc'ed NUL-terminated CIGAR strings, "<count><op>..." exactly as
- * CompressCigar prints them (src/alignment.cpp:17-33); free each with sa_free().
+ * CompressCigar prints them (src/alignment.cpp:17-33); free each with sa_free().  When the call fails,
+ * every entry of cigars is NULL and nothing is left to free.
  * ------------------------------------------------------------------------------------------- */
 int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
                         const char* const* targets, const uint32_t* target_lens, size_t n, int type,
@@ -191,7 +193,8 @@ int sa_minimize_batch_device(int device, void* stream, const sa_minimize_batch* 
                              void* d_workspace, size_t workspace_bytes);
 
 /* Minimizers, host buffers, sequences split over n_devices GPUs by length (0 = all visible).
- * out_triples[s] receives a malloc'ed array of out_counts[s] triples (free with sa_free). */
+ * out_triples[s] receives a malloc'ed array of out_counts[s] triples (free with sa_free); when the call
+ * fails, every entry of out_triples is NULL. */
 int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t n, uint32_t k,
                            uint32_t w, int variant, int n_devices, uint32_t** out_triples,
                            uint64_t* out_counts);

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsa_hip.so")
 SA_GLOBAL, SA_LOCAL, SA_SEMIGLOBAL = 0, 1, 2
 SA_MIN_BINARY, SA_MIN_DECIMAL = 0, 1
 (SA_OK, SA_ERR_HIP, SA_ERR_ARGUMENT, SA_ERR_WORKSPACE, SA_ERR_NO_DEVICE, SA_ERR_RANGE, SA_ERR_CAPACITY,
- SA_ERR_FORMAT) = range(8)
+ SA_ERR_FORMAT, SA_ERR_MEMORY) = range(9)
 SA_FMT_FASTA, SA_FMT_FASTQ = 0, 1
 SA_UNKNOWN_TYPE_SCORE = 9999
 

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 namespace sa {
@@ -217,7 +219,8 @@ struct Span {
   hipEvent_t a, b;
   int cls;
 };
-bool g_profile = false;
+std::atomic<bool> g_profile{false};
+std::mutex g_spans_mutex;  // batch calls may run on several host threads at once
 std::vector<Span> g_spans;
 
 struct Timed {
@@ -235,6 +238,7 @@ struct Timed {
   ~Timed() {
     if (!a) return;
     (void)hipEventRecord(b, stream);
+    std::lock_guard<std::mutex> g(g_spans_mutex);
     g_spans.push_back({a, b, cls});
   }
 };
@@ -421,7 +425,12 @@ int sa_align_profile_read(double ms[3], uint64_t launches[3]) {
     ms[i] = 0;
     launches[i] = 0;
   }
-  for (Span& sp : g_spans) {
+  std::vector<Span> spans;
+  {
+    std::lock_guard<std::mutex> g(g_spans_mutex);
+    spans.swap(g_spans);
+  }
+  for (Span& sp : spans) {
     float t = 0;
     SA_HIP_TRY(hipEventSynchronize(sp.b));
     SA_HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
@@ -430,7 +439,6 @@ int sa_align_profile_read(double ms[3], uint64_t launches[3]) {
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);
   }
-  g_spans.clear();
   return SA_OK;
 }
 
@@ -482,6 +490,10 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   const size_t total_blocks = ((size_t)b->n + pl.pairs_per_block - 1) / pl.pairs_per_block;
   size_t blocks_per_pass = (workspace_bytes - kFixedWorkspace) / pl.bytes_per_block;
   if (blocks_per_pass > total_blocks) blocks_per_pass = total_blocks;
+  // a pass stays within the grid limits of its launches (65 535 in y for the packing kernel's units, 2^32
+  // threads in all for the one-wavefront-per-pair kernels)
+  const size_t max_blocks = std::max<size_t>(1, ((size_t)1 << 22) / pl.pairs_per_block);
+  if (blocks_per_pass > max_blocks) blocks_per_pass = max_blocks;
   const size_t units_per_pass = blocks_per_pass * pl.units_per_block;
   size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 

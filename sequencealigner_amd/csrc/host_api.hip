@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 
 #include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -112,7 +114,10 @@ struct Lease {
   HostContext* c;
   explicit Lease(int device) : c(pool().acquire(device)) {}
   ~Lease() {
-    if (c) pool().release(c);
+    if (!c) return;
+    // a call that fails half way leaves work queued that still reads or writes the context's buffers
+    (void)hipStreamSynchronize(c->stream);
+    pool().release(c);
   }
 };
 
@@ -199,7 +204,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
                 const uint32_t* qlens, const char* const* targets, const uint32_t* tlens, int type,
                 int match, int mismatch, int gap, int32_t* scores, uint32_t* target_begin,
                 char** cigars, unsigned threads, unsigned mem_share) {
-  const uint32_t n = (uint32_t)idx.size();
+  const size_t n = idx.size();  // below 2^32 (checked by the caller)
   if (!n) return SA_OK;
   SA_HIP_TRY(hipSetDevice(device));
   Lease lease(device);
@@ -216,7 +221,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   uint64_t* hto = c.pin[TO].as<uint64_t>();
   uint64_t qtot = 0, ttot = 0;
   uint32_t maxq = 0, maxt = 0, minq = ~0u, mint = ~0u;
-  for (uint32_t j = 0; j < n; ++j) {
+  for (size_t j = 0; j < n; ++j) {
     const uint32_t i = idx[j];
     hqo[j] = qtot;
     hto[j] = ttot;
@@ -260,7 +265,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   b.d_q_off = c.dev[QO].as<uint64_t>();
   b.d_t = c.dev[T].as<uint8_t>();
   b.d_t_off = c.dev[TO].as<uint64_t>();
-  b.n = n;
+  b.n = (uint32_t)n;
   b.max_qlen = maxq;
   b.max_tlen = maxt;
   b.min_qlen = minq;
@@ -298,7 +303,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   if (want_cigar) SA_HIP_TRY(hipMemcpyAsync(c.pin[NRUNS].p, c.dev[NRUNS].p, n * 4, hipMemcpyDeviceToHost, st));
   SA_HIP_TRY(hipStreamSynchronize(st));
   trace.mark("device done");
-  for (uint32_t j = 0; j < n; ++j) {
+  for (size_t j = 0; j < n; ++j) {
     scores[idx[j]] = hscore[j];
     if (target_begin) target_begin[idx[j]] = htb[j];
   }
@@ -308,13 +313,13 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
     if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
     uint64_t* off = c.pin[OFF].as<uint64_t>();
     off[0] = 0;
-    for (uint32_t j = 0; j < n; ++j) off[j + 1] = off[j] + hnr[j];
+    for (size_t j = 0; j < n; ++j) off[j + 1] = off[j] + hnr[j];
     if ((rc = c.dev[OFF].ensure((n + 1) * 8)) || (rc = c.dev[COMPACT].ensure(off[n] * 4)) ||
         (rc = c.pin[RUNS].ensure(off[n] * 4)))
       return rc;
     SA_HIP_TRY(hipMemcpyAsync(c.dev[OFF].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gather_runs, dim3(n), dim3(64), 0, st, c.dev[RUNS].as<uint32_t>(),
-                       c.dev[NRUNS].as<uint32_t>(), c.dev[OFF].as<uint64_t>(), stride, n,
+    hipLaunchKernelGGL(gather_runs, dim3((uint32_t)n), dim3(64), 0, st, c.dev[RUNS].as<uint32_t>(),
+                       c.dev[NRUNS].as<uint32_t>(), c.dev[OFF].as<uint64_t>(), stride, (uint32_t)n,
                        c.dev[COMPACT].as<uint32_t>());
     SA_HIP_TRY(hipGetLastError());
     SA_HIP_TRY(hipMemcpyAsync(c.pin[RUNS].p, c.dev[COMPACT].p, off[n] * 4, hipMemcpyDeviceToHost, st));
@@ -328,7 +333,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
         if (!cigars[idx[j]]) oom = true;
       }
     });
-    if (oom) return fail(SA_ERR_ARGUMENT, "out of host memory");
+    if (oom) return fail(SA_ERR_MEMORY, "out of host memory");
     trace.mark("CIGAR text");
   }
   return SA_OK;
@@ -337,7 +342,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
 int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* const* seqs,
                    const uint32_t* lens, uint32_t k, uint32_t w, int variant, uint32_t** out_triples,
                    uint64_t* out_counts, unsigned threads) {
-  const uint32_t n = (uint32_t)idx.size();
+  const size_t n = idx.size();  // below 2^32 (checked by the caller)
   if (!n) return SA_OK;
   SA_HIP_TRY(hipSetDevice(device));
   Lease lease(device);
@@ -351,7 +356,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   uint64_t* ho = c.pin[OFF].as<uint64_t>();
   uint64_t tot = 0;
   uint32_t maxl = 0, minl = ~0u;
-  for (uint32_t j = 0; j < n; ++j) {
+  for (size_t j = 0; j < n; ++j) {
     ho[j] = tot;
     tot += lens[idx[j]];
     maxl = std::max(maxl, lens[idx[j]]);
@@ -365,8 +370,8 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   });
   memset(hs + tot, 0, 16);
   trace.mark("staging");
-  const uint64_t cap = sa_minimize_out_capacity(n, tot, k, w);
-  const size_t ws = sa_minimize_workspace_bytes(n, tot, maxl, k, w, variant);
+  const uint64_t cap = sa_minimize_out_capacity((uint32_t)n, tot, k, w);
+  const size_t ws = sa_minimize_workspace_bytes((uint32_t)n, tot, maxl, k, w, variant);
   if ((rc = c.dev[SEQ].ensure(tot + 16)) || (rc = c.dev[OFF].ensure((n + 1) * 8)) || (rc = c.dev[OUT].ensure(cap * 12)) ||
       (rc = c.dev[OOFF].ensure((n + 1) * 8)) || (rc = c.dev[STATUS].ensure(4)) || (rc = c.dev[WS].ensure(ws)))
     return rc;
@@ -375,7 +380,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   sa_minimize_batch b{};
   b.d_seq = c.dev[SEQ].as<uint8_t>();
   b.d_off = c.dev[OFF].as<uint64_t>();
-  b.n = n;
+  b.n = (uint32_t)n;
   b.total_len = tot;
   b.max_len = maxl;
   b.min_len = minl;
@@ -418,7 +423,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
       out_counts[idx[j]] = cnt;
     }
   });
-  if (oom) return fail(SA_ERR_ARGUMENT, "out of host memory");
+  if (oom) return fail(SA_ERR_MEMORY, "out of host memory");
   trace.mark("lists handed out");
   return SA_OK;
 }
@@ -444,8 +449,12 @@ int run_on_devices(int ndev, F f) {  // ndev tasks, one host thread each
   std::vector<std::thread> th;
   for (int d = 0; d < ndev; ++d)
     th.emplace_back([&, d]() {
-      rcs[d] = f(d);
-      if (rcs[d]) msgs[d] = last_error();
+      try {
+        rcs[d] = f(d);
+        if (rcs[d]) msgs[d] = last_error();
+      } catch (...) {  // nothing may leave a thread (or the C boundary) as an exception
+        rcs[d] = SA_ERR_MEMORY;
+      }
     });
   for (auto& t : th) t.join();
   for (int d = 0; d < ndev; ++d)
@@ -483,24 +492,31 @@ __global__ void triple_compact(const Triple* t, const uint32_t* flags, const uin
   if (i < n && flags[i]) out[pos[i]] = t[i];
 }
 
-}  // namespace
-}  // namespace sa
+// The two batch calls hand out malloc'ed results.  A call that fails gives back what it had handed out so
+// far and leaves NULL in every slot, and no C++ exception crosses the boundary.
+template <class F>
+int guarded(void** handed_out, size_t n, F body) {
+  if (handed_out) std::fill(handed_out, handed_out + n, nullptr);
+  int rc;
+  try {
+    rc = body();
+  } catch (const std::bad_alloc&) {
+    rc = fail(SA_ERR_MEMORY, "out of host memory");
+  } catch (const std::exception& e) {
+    rc = fail(SA_ERR_HIP, "unexpected failure: %s", e.what());
+  }
+  if (rc && handed_out)
+    for (size_t i = 0; i < n; ++i) {
+      free(handed_out[i]);
+      handed_out[i] = nullptr;
+    }
+  return rc;
+}
 
-using namespace sa;
-
-extern "C" {
-
-void sa_free(void* p) { free(p); }
-
-int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
-                        const char* const* targets, const uint32_t* target_lens, size_t n, int type,
-                        int match, int mismatch, int gap, int n_devices, int32_t* scores,
-                        uint32_t* target_begin, char** cigars) {
-  if (type < 0 || type > 2) return fail(SA_ERR_ARGUMENT, "unknown alignment type %d", type);
-  if (n == 0) return SA_OK;
-  if (!queries || !query_lens || !targets || !target_lens || !scores)
-    return fail(SA_ERR_ARGUMENT, "NULL argument");
-  if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many pairs");
+int align_batch_host(const char* const* queries, const uint32_t* query_lens,
+                            const char* const* targets, const uint32_t* target_lens, size_t n, int type,
+                            int match, int mismatch, int gap, int n_devices, int32_t* scores,
+                            uint32_t* target_begin, char** cigars) {
   const int ndev = pick_devices(n_devices);
   if (ndev == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
   // A device batch is planned for its longest query and target: pairs are grouped by size class (powers of
@@ -574,20 +590,46 @@ int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
   return SA_OK;
 }
 
+}  // namespace
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" {
+
+void sa_free(void* p) { free(p); }
+
+int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
+                        const char* const* targets, const uint32_t* target_lens, size_t n, int type,
+                        int match, int mismatch, int gap, int n_devices, int32_t* scores,
+                        uint32_t* target_begin, char** cigars) {
+  if (type < 0 || type > 2) return fail(SA_ERR_ARGUMENT, "unknown alignment type %d", type);
+  if (n == 0) return SA_OK;
+  if (!queries || !query_lens || !targets || !target_lens || !scores)
+    return fail(SA_ERR_ARGUMENT, "NULL argument");
+  if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many pairs");
+  return guarded((void**)cigars, n, [&] {
+    return align_batch_host(queries, query_lens, targets, target_lens, n, type, match, mismatch, gap,
+                            n_devices, scores, target_begin, cigars);
+  });
+}
+
 int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t n, uint32_t k,
                            uint32_t w, int variant, int n_devices, uint32_t** out_triples,
                            uint64_t* out_counts) {
   if (n == 0) return SA_OK;
   if (!seqs || !lens || !out_triples || !out_counts) return fail(SA_ERR_ARGUMENT, "NULL argument");
   if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many sequences");
-  const int ndev = pick_devices(n_devices);
-  if (ndev == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
-  std::vector<uint64_t> cost(n);
-  for (size_t i = 0; i < n; ++i) cost[i] = lens[i];
-  const auto shards = deal(cost, ndev, 16);
-  const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
-  return run_on_devices(ndev, [&](int d) {
-    return minimize_shard(d, shards[d], seqs, lens, k, w, variant, out_triples, out_counts, threads);
+  return guarded((void**)out_triples, n, [&] {
+    const int ndev = pick_devices(n_devices);
+    if (ndev == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
+    std::vector<uint64_t> cost(n);
+    for (size_t i = 0; i < n; ++i) cost[i] = lens[i];
+    const auto shards = deal(cost, ndev, 16);
+    const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
+    return run_on_devices(ndev, [&](int d) {
+      return minimize_shard(d, shards[d], seqs, lens, k, w, variant, out_triples, out_counts, threads);
+    });
   });
 }
 
