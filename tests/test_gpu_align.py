@@ -1,6 +1,7 @@
 """GPU parity tests for batched Align(): the HIP path (through the C-ABI) against the golden fixtures
 produced by the compiled reference and against the CPU restatement on seeded inputs.  Bit-exact bar:
 score, CIGAR string and target_begin must all be identical."""
+import ctypes as C
 import random
 
 import numpy as np
@@ -148,6 +149,26 @@ def test_small_workspace_multiple_passes(oracle):
     s, cg, tb = b.scores(), b.cigars(), b.target_begins()
     for i in range(0, 700, 7):
         assert (int(s[i]), cg[i], int(tb[i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
+
+
+def test_more_pairs_than_one_launch_holds(oracle):
+    """4.5 million tiny pairs: the batch exceeds what one pass may launch (2^22 pairs) although the
+    workspace would hold it, so the passes are cut by the launch limits."""
+    import torch
+    from sequencealigner_amd import align, synth
+    n = 4_500_000
+    rng = np.random.default_rng(77)
+    q = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 8))]
+    t = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 12))]
+    b = align.DeviceAlignBatch(q, t, 0, 1, -1, -1, want_cigar=False)
+    assert b.workspace_bytes == b.lib.sa_align_workspace_bytes(C.byref(b.batch), None)
+    b.run()
+    torch.cuda.synchronize()
+    qb, qo = synth.to_blob(q)
+    tb, to = synth.to_blob(t)
+    s, tbeg = oracle.align_batch(qb, qo, tb, to, 0, 1, -1, -1, True, 16)
+    assert np.array_equal(b.scores(), s)
+    assert np.array_equal(b.target_begins(), tbeg)
 
 
 def test_full_size_properties():
