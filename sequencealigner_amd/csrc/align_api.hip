@@ -292,14 +292,18 @@ int launch_lane_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback)
 
 template <int MODE, int K>
 int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
-                     const AlphabetInfo* alpha, hipStream_t stream, bool need_traceback) {
+                     AlphabetInfo* alpha, hipStream_t stream, bool need_traceback) {
   const uint32_t units = (a.pairs_in_pass + 127) / 128;
   {
     Timed tm(stream, 0);
     PackArgs pk{a.q, a.q_off, a.t, a.t_off, a.pair_base, a.pairs_in_pass, a.max_q, pl.t_pad,
-                (a.max_q + kPackTile - 1) / kPackTile, (pl.t_pad + kPackTile - 1) / kPackTile, qpk, tpk, alpha};
-    hipLaunchKernelGGL(pack_lane_pk16, dim3((pk.q_tiles + pk.t_tiles + 3) / 4, units), dim3(256), 0, stream,
-                       pk);
+                (a.max_q + kPackTile - 1) / kPackTile, (pl.t_pad + kPackTile - 1) / kPackTile, qpk, tpk, alpha, 0};
+    const dim3 grid((pk.q_tiles + pk.t_tiles + 3) / 4, units);
+    hipLaunchKernelGGL(pack_lane_pk16, grid, dim3(256), 0, stream, pk);
+    if (alpha) {  // returns at once unless the first launch met a byte the alphabet sample had missed
+      pk.again = 1;
+      hipLaunchKernelGGL(pack_lane_pk16, dim3(grid.x, std::min(units, 256u)), dim3(256), 0, stream, pk);
+    }
   }
   SA_HIP_TRY(hipGetLastError());
   Pk16Args x{qpk, tpk, pl.t_pad, pl.bias, units, alpha, pl.entry_match, pl.entry_mismatch};
@@ -376,7 +380,7 @@ int launch_wave_pk16(const Plan& pl, const AlignArgs& a, hipStream_t stream, boo
 
 template <int MODE>
 int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t* qpk, uint32_t* tpk,
-                const AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
+                AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE>(pl, a, stream, need_tb);
   if (pl.family == Family::WaveI32)
@@ -505,7 +509,7 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
     alpha = (AlphabetInfo*)d_workspace;
     SA_HIP_TRY(hipMemsetAsync(alpha, 0, sizeof(AlphabetInfo), stream));
     Timed tm(stream, 0);
-    hipLaunchKernelGGL(alphabet_scan, dim3(2048), dim3(256), 0, stream, b->d_q, b->d_q_off, b->d_t,
+    hipLaunchKernelGGL(alphabet_scan, dim3(kScanBlocks), dim3(256), 0, stream, b->d_q, b->d_q_off, b->d_t,
                        b->d_t_off, b->n, alpha);
     hipLaunchKernelGGL(alphabet_table, dim3(1), dim3(256), 0, stream, alpha);
     SA_HIP_TRY(hipGetLastError());

@@ -93,12 +93,17 @@ struct Pk16Args {
 };
 
 // Result of scanning a batch's bytes: with at most four distinct symbols the substitution score of a
-// cell is a table lookup (one v_perm_b32) instead of compare + select arithmetic.
+// cell is a table lookup (one v_perm_b32) instead of compare + select arithmetic.  A large batch is only
+// sampled (alphabet_scan); the packing kernel, which reads every byte anyway, checks the sample's verdict
+// and raises `violated` at the first byte the sample had not seen - the pass is then packed again and
+// filled in the symbols form.
 struct AlphabetInfo {
-  uint32_t present[8];  // bit b set: byte value b occurs in the batch
-  uint32_t small;       // 1: at most 4 distinct bytes, code[] maps them to 0..3
+  uint32_t present[8];  // bit b set: byte value b occurs in the bytes that were scanned
+  uint32_t small;       // 1: at most 4 distinct bytes, code[] maps them to 0..3 (kUnseen for the others)
+  uint32_t violated;    // 1: a byte outside code[] turned up while packing; the tables form is off
   uint8_t code[256];
 };
+constexpr uint32_t kUnseen = 0x80;
 
 // Number of direction dwords a lane writes per query column and strip: 2 planes per group of 16 rows.
 template <int K>
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void fill_lane_pk16(AlignArgs a, Pk16Args x) {
   st.final2 = 0;
 
   // The batch scan decides (on the device, uniformly for the launch) which packed form was written.
-  const bool tables = TABLES && x.alpha->small;
+  const bool tables = TABLES && x.alpha->small && !x.alpha->violated;
   if (tables) {
     const uint32_t* qpk = x.qpk + (uint64_t)unit * a.max_q * 64 + lane;
     lane_pk16_strips<MODE, K, SH, true>(a, x, nfull, rem, nstrips, maxQ, lane, qpk, tpk, brow, dirs,
@@ -514,9 +519,14 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   }
 }
 
-// Marks which byte values occur in the query and target blobs of a batch (grid-stride over bytes).  A
-// workgroup collects them in a 256-entry LDS table indexed by the byte itself (plain stores of 1: every
-// writer writes the same value), then ORs the entries that were hit into the global bit set.
+// Marks which byte values occur in the query and target blobs of a batch: every thread looks at up to
+// kScanWords 8-byte words, the words spread evenly over the blob - all of them when the blob has no more
+// words than that allows (2 MiB with the grid the caller launches), a sample otherwise.  A workgroup
+// collects the bytes in a 256-entry LDS table indexed by the byte itself (plain stores of 1: every writer
+// writes the same value), then ORs the entries that were hit into the global bit set - a few atomics per
+// workgroup, all on the same words, which is why the grid is kept small.
+constexpr uint32_t kScanWords = 4;
+constexpr uint32_t kScanBlocks = 256;
 __global__ __launch_bounds__(256) void alphabet_scan(const uint8_t* q, const uint64_t* q_off,
                                                      const uint8_t* t, const uint64_t* t_off, uint32_t n,
                                                      AlphabetInfo* info) {
@@ -532,7 +542,12 @@ __global__ __launch_bounds__(256) void alphabet_scan(const uint8_t* q, const uin
     // 8 bytes per thread and iteration through aligned loads (the blob is 8-byte aligned and readable
     // up to 8 bytes past its end)
     const uint64_t w0 = b0 & ~7ull, w1 = (b1 + 7) & ~7ull;
-    for (uint64_t w = w0 + 8 * tid; w < w1; w += 8 * nthreads) {
+    const uint64_t slots = nthreads * kScanWords;
+    const uint64_t every = ((w1 - w0) / 8 + slots - 1) / slots;  // 1: all words
+#pragma unroll
+    for (uint32_t it = 0; it < kScanWords; ++it) {
+      const uint64_t w = w0 + 8 * (tid + it * nthreads) * every;
+      if (w >= w1) break;
       const uint64_t word = *reinterpret_cast<const uint64_t*>(base + w);
       const bool inner = w >= b0 && w + 8 <= b1;
 #pragma unroll
@@ -560,7 +575,7 @@ __global__ void alphabet_table(AlphabetInfo* info) {  // one workgroup of 256 th
       below += __builtin_popcount(m & ((1u << (b & 31)) - 1u));
   }
   const bool on = (info->present[b >> 5] >> (b & 31)) & 1u;
-  info->code[b] = (uint8_t)(on && below < 4 ? below : 0);
+  info->code[b] = (uint8_t)(on && below < 4 ? below : kUnseen);
   if (b == 0) info->small = total <= 4 ? 1u : 0u;
 }
 
@@ -582,19 +597,23 @@ struct PackArgs {
   uint32_t q_tiles, t_tiles; // tiles of the query side / target side
   uint32_t* qpk;
   uint32_t* tpk;
-  const AlphabetInfo* alpha;
+  AlphabetInfo* alpha;
+  uint32_t again;  // 1: the launch that repeats the packing in the symbols form if `violated` was raised
 };
 
 __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
   __shared__ uint8_t code[256];
-  const bool tables = a.alpha && a.alpha->small;
+  if (a.again && !a.alpha->violated) return;
+  const bool tables = a.alpha && a.alpha->small && !a.alpha->violated;
   if (tables) code[threadIdx.x] = a.alpha->code[threadIdx.x];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= a.q_tiles + a.t_tiles) return;
   const bool is_query = tile < a.q_tiles;
-  const uint32_t unit = blockIdx.y;
+  const uint32_t units = (a.pairs_in_pass + 127) / 128;
+  // gridDim.y is the number of units, or fewer for the repeat launch (which mostly has nothing to do)
+  for (uint32_t unit = blockIdx.y; unit < units; unit += gridDim.y) {
   const uint32_t t0 = (is_query ? tile : tile - a.q_tiles) * kPackTile;
   const uint8_t* seq = is_query ? a.q : a.t;
   const uint64_t* off = is_query ? a.q_off : a.t_off;
@@ -619,23 +638,35 @@ __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
     wb[j] = pos < lenB ? *reinterpret_cast<const uint64_t*>(seq + offB + pos) : 0;
   }
   const uint32_t pad = is_query ? kQueryPad : kTargetPad;
+  uint32_t unseen = 0;
+  // the word index is unrolled (registers), the byte index is a loop: the compact form keeps more
+  // wavefronts resident, which matters more here than the instruction count
 #pragma unroll
-  for (uint32_t c = 0; c < kPackTile; ++c) {
-    const uint32_t pos = t0 + c;
-    if (pos >= len_cap) break;
-    const bool inA = pos < lenA, inB = pos < lenB;
-    const uint32_t ba = (uint32_t)(wa[c >> 3] >> (8 * (c & 7))) & 0xFFu;
-    const uint32_t bb = (uint32_t)(wb[c >> 3] >> (8 * (c & 7))) & 0xFFu;
-    uint32_t v;
-    if (!tables) {
-      v = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
-    } else if (is_query) {
-      v = (inA ? (uint32_t)code[ba] : 0xFFFFu) | ((inB ? (uint32_t)code[bb] : 0xFFFFu) << 16);
-    } else {
-      const uint32_t sa = inA ? (uint32_t)code[ba] : 0x0Cu, sb = inB ? 4u + code[bb] : 0x0Cu;
-      v = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
+  for (uint32_t j = 0; j < 8; ++j) {
+    uint64_t ra = wa[j], rb = wb[j];
+#pragma unroll 1
+    for (uint32_t c = 8 * j; c < 8 * j + 8; ++c, ra >>= 8, rb >>= 8) {
+      const uint32_t pos = t0 + c;
+      if (pos >= len_cap) break;
+      const bool inA = pos < lenA, inB = pos < lenB;
+      const uint32_t ba = (uint32_t)ra & 0xFFu, bb = (uint32_t)rb & 0xFFu;
+      uint32_t v;
+      if (!tables) {
+        v = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
+      } else {
+        const uint32_t ca = inA ? (uint32_t)code[ba] : 0u, cb = inB ? (uint32_t)code[bb] : 0u;
+        unseen |= ca | cb;
+        if (is_query) {
+          v = (inA ? ca : 0xFFFFu) | ((inB ? cb : 0xFFFFu) << 16);
+        } else {
+          const uint32_t sa = inA ? ca : 0x0Cu, sb = inB ? 4u + cb : 0x0Cu;
+          v = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
+        }
+      }
+      out[(uint64_t)c * 64] = v;
     }
-    out[(uint64_t)c * 64] = v;
+  }
+  if (unseen & kUnseen) a.alpha->violated = 1;
   }
 }
 

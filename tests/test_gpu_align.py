@@ -171,6 +171,40 @@ def test_more_pairs_than_one_launch_holds(oracle):
     assert np.array_equal(b.target_begins(), tbeg)
 
 
+@pytest.mark.parametrize("rare", ["fifth symbol", "fourth symbol"])
+def test_symbol_the_alphabet_sample_misses(oracle, rare):
+    """A batch of more than 4 MB has its alphabet sampled, not scanned.  One byte in a word the sample
+    skips (word 1 of a blob) is the only occurrence of a symbol: the packing kernel must notice it and the
+    batch must still come out exact."""
+    import torch
+    from sequencealigner_amd import align, synth
+    n = 30_000
+    q, t = synth.pairs_short_read_window(n, seed=21)
+    q, t = np.array(q), np.array(t)
+    if rare == "fifth symbol":
+        q[0, 9] = ord("N")
+        t[0, 12] = ord("N")
+    else:  # only A, C, G elsewhere; a single T
+        q[q == ord("T")] = ord("G")
+        t[t == ord("T")] = ord("G")
+        t[0, 12] = ord("T")
+    for typ in (1, 0):
+        b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1)
+        assert b.kernel_name() == "lane_pk16"
+        b.run()
+        torch.cuda.synchronize()
+        # head of the workspace: 8 words of byte-presence bits, then "small alphabet", then "violated"
+        info = b.d_ws[:40].cpu().numpy().view(np.uint32)
+        assert info[8] == 1 and info[9] == 1, "the sample was expected to miss the symbol"
+        qb, qo = synth.to_blob(q)
+        tb, to = synth.to_blob(t)
+        s, tbeg = oracle.align_batch(qb, qo, tb, to, typ, 1, -1, -1, True, 16)
+        assert np.array_equal(b.scores(), s)
+        assert np.array_equal(b.target_begins(), tbeg)
+        for i in (0, 1, n - 1):
+            assert b.cigars([i])[0] == oracle.align(bytes(q[i]), bytes(t[i]), typ, 1, -1, -1)[1]
+
+
 def test_full_size_properties():
     """Full benchmark size (scaled to 200k pairs to bound the time): every CIGAR must re-score to the
     reported score and consume exactly the aligned part of query and target."""
