@@ -379,8 +379,8 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   constexpr int C = Fmt::C;
   constexpr uint32_t STRIP = 64 * C;
   constexpr uint32_t TS = Fmt::kTileSteps;
-  constexpr uint32_t TW = 16;                           // lanes (column blocks) of one LDS tile
   constexpr uint32_t WPV = 16 / sizeof(word_t);         // words per 16-byte vector
+  constexpr uint32_t TW = WPV > 8 ? WPV : 8;            // lanes (column blocks) of one LDS tile
   constexpr uint32_t VPR = TW / WPV;                    // vectors per tile row
   constexpr uint32_t kVecPerLane = TS * VPR / 64;       // vectors a lane moves per tile
   static_assert(TW % WPV == 0 && (TS * VPR) % 64 == 0, "tile shape");
