@@ -171,7 +171,7 @@ def test_more_pairs_than_one_launch_holds(oracle):
     assert np.array_equal(b.target_begins(), tbeg)
 
 
-@pytest.mark.parametrize("rare", ["fifth symbol", "fourth symbol"])
+@pytest.mark.parametrize("rare", ["fifth symbol", "fourth symbol", "fifth symbol in a later pass"])
 def test_symbol_the_alphabet_sample_misses(oracle, rare):
     """A batch of more than 4 MB has its alphabet sampled, not scanned.  One byte in a word the sample
     skips (word 1 of a blob) is the only occurrence of a symbol: the packing kernel must notice it and the
@@ -181,15 +181,24 @@ def test_symbol_the_alphabet_sample_misses(oracle, rare):
     n = 30_000
     q, t = synth.pairs_short_read_window(n, seed=21)
     q, t = np.array(q), np.array(t)
+    workspace = None
     if rare == "fifth symbol":
         q[0, 9] = ord("N")
         t[0, 12] = ord("N")
+    elif rare == "fifth symbol in a later pass":
+        # pair 29 000 starts at query word 543 750, a multiple of the sampling step 3; its byte 9 is in the
+        # next word.  A quarter of the full workspace: the pair is met in the last of several passes, after
+        # earlier passes have run in the tables form.
+        q[29_000, 9] = ord("N")
+        probe = align.DeviceAlignBatch(q, t, 1, 1, -1, -1)
+        workspace = (probe.lib.sa_align_workspace_bytes(C.byref(probe.batch), None) - 1024) // 4 + 1024
+        del probe
     else:  # only A, C, G elsewhere; a single T
         q[q == ord("T")] = ord("G")
         t[t == ord("T")] = ord("G")
         t[0, 12] = ord("T")
     for typ in (1, 0):
-        b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1)
+        b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1, workspace_bytes=workspace)
         assert b.kernel_name() == "lane_pk16"
         b.run()
         torch.cuda.synchronize()
