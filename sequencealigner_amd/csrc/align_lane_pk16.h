@@ -174,7 +174,10 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
         const uint32_t seg = 16 * c + (lane >> 2), col = 2 * (lane & 3);
         const uint2 w0 = stage[(g * kColBlock + col) * 64 + seg];
         const uint2 w1 = stage[(g * kColBlock + col + 1) * 64 + seg];
-        *reinterpret_cast<uint4*>(tile + c * 256 + lane * 4) = make_uint4(w0.x, w0.y, w1.x, w1.y);
+        // written once, read once by the traceback after 13 GB more have gone by: keep it out of the caches
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{w0.x, w0.y, w1.x, w1.y},
+                                    reinterpret_cast<u32x4*>(tile + c * 256 + lane * 4));
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
           v = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
         }
       }
-      out[(uint64_t)c * 64] = v;
+      __builtin_nontemporal_store(v, &out[(uint64_t)c * 64]);  // read once, by the fill, much later
     }
   }
   if (unseen & kUnseen) a.alpha->violated = 1;

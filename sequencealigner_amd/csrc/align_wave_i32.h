@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
           lin_prev = lin;
         }
         flags(C - 1, lin_prev);
-        drow[(uint64_t)st * 64] = (word_t)acc;
+        // written once, read once by the traceback: keep it out of the caches
+        __builtin_nontemporal_store((word_t)acc, drow + (uint64_t)st * 64);
         ldiag = recv;
         lastcol = left;
         if (MODE == SA_LOCAL) {

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
             lin_prev = lin;
           }
           flags(C - 1, lin_prev);
-          drow[(uint64_t)st * 64] = make_uint2(acc0, acc1);
+          // written once, read once by the traceback: keep it out of the caches
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_nontemporal_store(u32x2{acc0, acc1}, reinterpret_cast<u32x2*>(drow + (uint64_t)st * 64));
           ldiag = recv;
           lastcol = left;
           // a pair's last column is in this strip; Global wants it on one step only, the pair's last row
