@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void fill_lane_i32(AlignArgs a) {
         up = m;
         word |= dir << (2 * (k & 15));
         if ((k & 15) == 15) {
-          dirs[((uint64_t)(s * a.max_q + (r - 1)) * (K / 16) + (k >> 4)) * 64 + lane] = word;
+          // written once, read once by the traceback: keep it out of the caches
+          __builtin_nontemporal_store(word, &dirs[((uint64_t)(s * a.max_q + (r - 1)) * (K / 16) + (k >> 4)) * 64 + lane]);
           word = 0;
         }
       }
