@@ -425,8 +425,10 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
     uint32_t d;
+    uint32_t len = 1;  // moves of kind d taken in this iteration
     if (i == 0 || r == 0) {
       d = border_dir<MODE>(i, r, a.gap);  // None, Left or Up
+      len = (d == DIR_LEFT) ? r : i;      // a border is followed to its end
     } else {
       if (MODE == SA_LOCAL && remaining == 0) break;  // an inner cell with score 0 is None
       const uint32_t c = r - 1;
@@ -525,27 +527,37 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         continue;
       }
       d = __builtin_amdgcn_readfirstlane(dx);  // lane 0 holds the current cell
+      if (d == DIR_UP) {
+        // Lane x looks at the cell x rows further up in the same column, (i - x, r): one step earlier in
+        // the same lane's words.  A long gap in the query (a chain that spans far more reference than the
+        // read is long) is walked 64 rows per iteration instead of one.  (Local: the score grows on the
+        // way up, gap < 0, so no cell of the run is a zero cell.)
+        const bool okx = lane < i && st >= tile_lo + lane;
+        const uint32_t ux =
+            okx ? Fmt::decode(tile[(st - lane - tile_lo) * TW + (L - tile_lb)], c % C, half) : (uint32_t)DIR_NONE;
+        const uint64_t um = __ballot(okx && ux == DIR_UP);
+        len = ~um ? (uint32_t)__builtin_ctzll(~um) : 64u;  // >= 1: lane 0 is the current cell
+      }
     }
     if (d == DIR_NONE || d == DIR_DIAG) break;  // (an inner Diag cell is handled above: None at score 0)
     uint32_t op;
     if (d == DIR_LEFT) {
       op = SA_OP_I;
-      if (MODE == SA_LOCAL) remaining -= a.gap;
-      --r;
+      r -= len;
     } else {
       op = SA_OP_D;
-      if (MODE == SA_LOCAL) remaining -= a.gap;
-      --i;
+      i -= len;
     }
+    if (MODE == SA_LOCAL) remaining -= a.gap * (int)len;
     if (op == cur_op) {
-      ++cur_len;
+      cur_len += len;
     } else {
       if (cur_len) {
         ++nruns;
         if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
       }
       cur_op = op;
-      cur_len = 1;
+      cur_len = len;
     }
   }
   if (lane != 0) return;

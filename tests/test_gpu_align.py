@@ -271,6 +271,26 @@ def test_long_pairs_vs_oracle(oracle, wave_mode):
             _run_group(_oracle_cases(oracle, [(bytes(qq).decode(), bytes(tt).decode())], typ, 1, -1, -1))
 
 
+def test_long_gap_runs_vs_oracle(oracle, wave_mode):
+    """Queries stitched from two distant pieces of the target, and queries much shorter or longer than the
+    target: the paths hold runs of hundreds of D (or I) moves, inside the matrix and along its borders."""
+    rng = random.Random(99)
+    pairs = []
+    for n in range(10):
+        T = rng.randint(1500, 2600)
+        t = "".join(rng.choice("ACGT") for _ in range(T))
+        a, b = rng.randint(0, 200), rng.randint(T - 600, T - 300)
+        piece = rng.randint(150, 280)
+        q = t[a:a + piece] + t[b:b + piece]           # a gap of ~1000-2000 target rows in the middle
+        q = "".join(c if rng.random() > 0.03 else rng.choice("ACGT") for c in q)
+        pairs.append((q, t))
+        pairs.append((t, q))                           # and the same as a run of insertions
+    pairs.append(("ACGTACGTAC", "T" * 700 + "ACGTACGTAC" + "G" * 900))
+    pairs.append(("T" * 700 + "ACGTACGTAC" + "G" * 900, "ACGTACGTAC"))
+    for typ, (m, x, g) in ((0, (1, -1, -1)), (2, (1, -1, -1)), (1, (2, -3, -1)), (0, (2, -2, 0)), (1, (1, -1, 0))):
+        _run_group(_oracle_cases(oracle, pairs, typ, m, x, g))
+
+
 def test_cooperative_single_long_pair_vs_oracle(oracle):
     """One 20 kbp x 19 kbp pair: 40 strips in flight at once, each following its left neighbour."""
     from sequencealigner_amd import align, synth
