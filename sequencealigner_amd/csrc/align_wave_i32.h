@@ -537,6 +537,16 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
             okx ? Fmt::decode(tile[(st - lane - tile_lo) * TW + (L - tile_lb)], c % C, half) : (uint32_t)DIR_NONE;
         const uint64_t um = __ballot(okx && ux == DIR_UP);
         len = ~um ? (uint32_t)__builtin_ctzll(~um) : 64u;  // >= 1: lane 0 is the current cell
+      } else if (d == DIR_LEFT) {
+        // the same along the row: lane x looks at (i, r - x), as far as the strip and the tile reach
+        const bool inx = lane < r && c - lane >= s * STRIP && c >= lane;
+        const uint32_t cl = inx ? c - lane : c;
+        const uint32_t Ll = (cl % STRIP) / C, stl = i + Ll;
+        const bool okx = inx && Ll >= tile_lb && stl >= tile_lo;
+        const uint32_t lx =
+            okx ? Fmt::decode(tile[(stl - tile_lo) * TW + (Ll - tile_lb)], cl % C, half) : (uint32_t)DIR_NONE;
+        const uint64_t lm = __ballot(okx && lx == DIR_LEFT);
+        len = ~lm ? (uint32_t)__builtin_ctzll(~lm) : 64u;
       }
     }
     if (d == DIR_NONE || d == DIR_DIAG) break;  // (an inner Diag cell is handled above: None at score 0)
