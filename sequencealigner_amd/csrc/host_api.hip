@@ -603,12 +603,12 @@ int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
                         const char* const* targets, const uint32_t* target_lens, size_t n, int type,
                         int match, int mismatch, int gap, int n_devices, int32_t* scores,
                         uint32_t* target_begin, char** cigars) {
-  if (type < 0 || type > 2) return fail(SA_ERR_ARGUMENT, "unknown alignment type %d", type);
-  if (n == 0) return SA_OK;
-  if (!queries || !query_lens || !targets || !target_lens || !scores)
-    return fail(SA_ERR_ARGUMENT, "NULL argument");
-  if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many pairs");
+  if (n == 0) return (type < 0 || type > 2) ? fail(SA_ERR_ARGUMENT, "unknown alignment type %d", type) : SA_OK;
   return guarded((void**)cigars, n, [&] {
+    if (type < 0 || type > 2) return fail(SA_ERR_ARGUMENT, "unknown alignment type %d", type);
+    if (!queries || !query_lens || !targets || !target_lens || !scores)
+      return fail(SA_ERR_ARGUMENT, "NULL argument");
+    if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many pairs");
     return align_batch_host(queries, query_lens, targets, target_lens, n, type, match, mismatch, gap,
                             n_devices, scores, target_begin, cigars);
   });
@@ -618,9 +618,9 @@ int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t
                            uint32_t w, int variant, int n_devices, uint32_t** out_triples,
                            uint64_t* out_counts) {
   if (n == 0) return SA_OK;
-  if (!seqs || !lens || !out_triples || !out_counts) return fail(SA_ERR_ARGUMENT, "NULL argument");
-  if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many sequences");
   return guarded((void**)out_triples, n, [&] {
+    if (!seqs || !lens || !out_triples || !out_counts) return fail(SA_ERR_ARGUMENT, "NULL argument");
+    if (n > 0xFFFFFFF0ull) return fail(SA_ERR_ARGUMENT, "too many sequences");
     const int ndev = pick_devices(n_devices);
     if (ndev == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
     std::vector<uint64_t> cost(n);

@@ -110,3 +110,25 @@ def test_file_name_tests_split_and_stats():
     # N50 as the mapper computes it: file order, first fragment at which the running sum exceeds half
     assert st == {"count": 4, "total": 1100, "longest": 500, "longest_name": "c", "shortest": 100,
                   "shortest_name": "b", "average": 275.0, "n50": 500}
+
+
+def test_failed_host_call_hands_nothing_out():
+    """A host batch call that fails leaves NULL in every result slot (nothing for the caller to free) and
+    reports through its return code; checked on calls that fail before any GPU work."""
+    import ctypes as C
+    from sequencealigner_amd import capi
+    lib = capi.lib()
+    n = 3
+    seqs = (C.c_char_p * n)(b"ACGT", b"ACGTACGT", b"AC")
+    lens = (C.c_uint32 * n)(4, 8, 2)
+    scores = (C.c_int32 * n)()
+    tb = (C.c_uint32 * n)()
+    cig = (C.c_void_p * n)(0xDEAD0, 0xDEAD0, 0xDEAD0)   # stale values a careless caller would free
+    rc = lib.sa_align_batch_host(seqs, lens, seqs, lens, n, 7, 1, -1, -1, 0, scores, tb, cig)
+    assert rc == capi.SA_ERR_ARGUMENT and b"alignment type" in lib.sa_last_error()
+    assert [cig[i] for i in range(n)] == [None] * n
+    out = (C.c_void_p * n)(0xDEAD0, 0xDEAD0, 0xDEAD0)
+    counts = (C.c_uint64 * n)()
+    rc = lib.sa_minimize_batch_host(None, lens, n, 15, 5, 0, 0, out, counts)
+    assert rc == capi.SA_ERR_ARGUMENT
+    assert [out[i] for i in range(n)] == [None] * n
