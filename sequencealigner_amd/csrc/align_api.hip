@@ -137,7 +137,7 @@ Plan make_plan(const sa_align_batch& b) {
     const double strip_eff = max_q / (std::ceil(max_q / 1024.0) * 1024.0) * max_t / (max_t + 63.0);
     uint32_t unused_bias = 0;
     const bool wpk = !force_i32 && wave_pk16_applicable(b, &unused_bias);
-    const double wave_rate = std::min(b.n / (wpk ? 6144.0 : 2048.0), 1.0) * (wpk ? 4.1 : 3.0) * strip_eff;
+    const double wave_rate = std::min(b.n / (wpk ? 6144.0 : 2048.0), 1.0) * (wpk ? 5.0 : 3.0) * strip_eff;
     want_wave = wave_rate > lane_rate;
   }
   if (b.type == SA_LOCAL &&
