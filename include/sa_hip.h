@@ -59,6 +59,21 @@ int sa_device_count(void);
 /* "gfx950..." name of the device's architecture, or NULL. */
 const char* sa_device_arch(int device);
 
+/* Tuning and test options of the process (no counterpart in the reference).  Every option starts from an
+ * environment variable that is read once, when the library first needs an option; afterwards only this call
+ * changes it, so that no call reads the environment while another thread may be changing it.
+ *   "force_i32"     (SA_FORCE_I32)     1: never use the packed 16-bit kernels
+ *   "force_family"  (SA_FORCE_FAMILY=lane|wave)  0 automatic, 1 lane kernels, 2 wavefront kernels
+ *   "force_coop"    (SA_FORCE_COOP)    -1 automatic, 0 / 1: cooperative wavefront kernel off / on where possible
+ *   "no_tables"     (SA_NO_TABLES)     1: packed lane kernel without score tables
+ *   "coop_c"        (SA_COOP_C)        columns per lane of the cooperative kernel, 0 automatic
+ *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64
+ *   "min_chunk"     (SA_MIN_CHUNK)     windows per minimizer chunk, 0 automatic
+ *   "fake_devices"  (SA_FAKE_DEVICES)  the host batch calls deal their units to this many shards, all run on
+ *                                      GPU 0 at the same time (the multi-GPU path on a one-GPU machine)
+ * A call that is planning a batch while an option changes may see either value; set options between calls. */
+int sa_set_option(const char* name, long value);
+
 /* ---------------------------------------------------------------------------------------------
  * Alignment, device-resident batch.  Takes the place of one Align() call per pair
  * (reference src/alignment.cpp:353-374, called per read at src/mapper.cpp:423).
@@ -143,7 +158,9 @@ int sa_cigar_stats_device(int device, void* stream, uint32_t n, const uint32_t* 
  * GPU's own stream and gathered back in input order - no inter-GPU communication.  Pairs are grouped by
  * size class (powers of two of query and target length) and each class runs as a batch of its own.
  * cigars (optional) receives n malloc'ed NUL-terminated CIGAR strings, "<count><op>..." exactly as
- * CompressCigar prints them (src/alignment.cpp:17-33); free each with sa_free().  When the call fails,
+ * CompressCigar prints them (src/alignment.cpp:17-33); free each with sa_free().  target_begin (optional)
+ * receives what Align() stores in *target_begin for the same arguments: for Global / Semiglobal without
+ * `cigars` that is 1 (the reference then inspects an empty CIGAR string).  When the call fails,
  * every entry of cigars is NULL and nothing is left to free.
  * ------------------------------------------------------------------------------------------- */
 int sa_align_batch_host(const char* const* queries, const uint32_t* query_lens,
@@ -289,6 +306,14 @@ int sa_unpack2bit_device(int device, void* stream, const uint64_t* d_packed, con
  * records can be aligned without visiting the host. */
 int sa_gather_spans_device(int device, void* stream, const uint8_t* d_src, const uint64_t* d_src_start,
                            const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst);
+
+/* The dealing rule of the two host batch calls above, for schedulers and tests (pure host code, no GPU needed):
+ * units are ordered by decreasing cost (stable; left in input order when all costs are equal) and dealt to
+ * n_shards shards in blocks of `block` units, every block to the shard with the smallest total cost so far.  shard_of[u] = shard of unit u; order (optional, n
+ * entries) = the units shard by shard, each shard in the order it processes them.  This is the device batch
+ * queue's replacement for the reference's one-task-per-read submission loop (src/mapper.cpp:665-675). */
+int sa_shard_units(const uint64_t* cost, size_t n, int n_shards, uint32_t block, uint32_t* shard_of,
+                   uint32_t* order);
 
 /* removeDuplicate on the device (reference src/utility.cpp:8-26): sorts n triples in place by
  * (value, position, strand) and writes the distinct ones to out (capacity n); *out_n = their number. */

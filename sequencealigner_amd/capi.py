@@ -62,6 +62,7 @@ SYMBOLS = [
     ("sa_last_error", C.c_char_p, []),
     ("sa_device_count", C.c_int, []),
     ("sa_device_arch", C.c_char_p, [C.c_int]),
+    ("sa_set_option", C.c_int, [C.c_char_p, C.c_long]),
     ("sa_align_workspace_bytes", C.c_size_t, [C.POINTER(AlignBatch), C.POINTER(C.c_size_t)]),
     ("sa_align_batch_device", C.c_int,
      [C.c_int, C.c_void_p, C.POINTER(AlignBatch), C.c_void_p, C.c_size_t]),
@@ -91,6 +92,7 @@ SYMBOLS = [
     ("sa_unpack2bit_device", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("sa_gather_spans_device", C.c_int,
      [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("sa_shard_units", C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("sa_remove_duplicate_host", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
 ]
@@ -116,6 +118,11 @@ def lib():
             fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """sa_set_option(): tuning / test options of the process (include/sa_hip.h lists them)."""
+    check(lib().sa_set_option(name.encode(), int(value)))
 
 
 def check(code):

@@ -30,6 +30,26 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+Options& options() {
+  static Options* o = [] {
+    Options* x = new Options();
+    auto num = [](const char* name, long dflt) {
+      const char* e = getenv(name);
+      return e ? atol(e) : dflt;
+    };
+    x->force_i32 = getenv("SA_FORCE_I32") != nullptr;
+    if (const char* f = getenv("SA_FORCE_FAMILY")) x->force_family = !strcmp(f, "wave") ? 2 : 1;
+    x->force_coop = num("SA_FORCE_COOP", -1);
+    x->no_tables = getenv("SA_NO_TABLES") != nullptr;
+    x->coop_c = num("SA_COOP_C", 0);
+    x->pk16_k = num("SA_PK16_K", 48);
+    x->min_chunk = num("SA_MIN_CHUNK", 0);
+    x->fake_devices = num("SA_FAKE_DEVICES", 0);
+    return x;
+  }();
+  return *o;
+}
+
 namespace {
 
 constexpr int kLaneI32K = 32;     // target rows per register strip of the 32-bit lane kernel
@@ -105,21 +125,18 @@ bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
 }
 
 int pk16_strip_rows() {
-  static int k = [] {
-    const char* e = getenv("SA_PK16_K");
-    int v = e ? atoi(e) : 48;
-    return (v == 32 || v == 48 || v == 64) ? v : 48;
-  }();
-  return k;
+  const long v = options().pk16_k;
+  return (v == 32 || v == 48 || v == 64) ? (int)v : 48;
 }
 
-Plan make_plan(const sa_align_batch& b) {
+Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
   Plan pl{};
   const uint32_t max_q = b.max_qlen ? b.max_qlen : 1, max_t = b.max_tlen ? b.max_tlen : 1;
   uint32_t bias = 0;
   const int K16 = pk16_strip_rows();
-  const bool force_i32 = getenv("SA_FORCE_I32") != nullptr;
-  const char* force_family = getenv("SA_FORCE_FAMILY");
+  const Options& opt = options();
+  const bool force_i32 = opt.force_i32 != 0;
+  const long force_family = opt.force_family;  // 1 lane, 2 wave
   // The lane kernels put 64 or 128 pairs on a wavefront, the wavefront kernels one pair (or one strip of
   // a pair): which family fills the GPU better depends on the batch.  Rough throughput estimates (TCUPS,
   // measured on MI355X) decide; pairs longer than 2048 always take the wavefront kernels.
@@ -128,7 +145,7 @@ Plan make_plan(const sa_align_batch& b) {
   const bool pk16_ok = !force_i32 && lane_pk16_applicable(b, K16, &bias);
   bool want_wave;
   if (force_family) {
-    want_wave = !strcmp(force_family, "wave");
+    want_wave = force_family == 2;
   } else if (max_q > 2048 || max_t > 2048) {
     want_wave = true;
   } else {
@@ -148,15 +165,12 @@ Plan make_plan(const sa_align_batch& b) {
     // Few long pairs: spread every pair's strips over as many wavefronts (narrow strips, all resident).
     // columns per lane of the cooperative kernel: 4 (more, shorter steps in flight) while all wavefronts of
     // the batch stay resident, else 8; SA_COOP_C=4|8 pins it
-    static const int coop_env = [] {
-      const char* e = getenv("SA_COOP_C");
-      const int v = e ? atoi(e) : 0;
-      return v == 4 || v == 8 ? v : 0;
-    }();
+    const long coop_opt = opt.coop_c;
+    const int coop_env = coop_opt == 4 || coop_opt == 8 ? (int)coop_opt : 0;
     const int coop_c = coop_env ? coop_env : ((uint64_t)b.n * ((max_q + 255) / 256) <= 2048 ? 4 : 8);
     const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
-    const char* force_coop = getenv("SA_FORCE_COOP");
-    pl.coop = b.n * strips8 <= 2048 && (force_coop ? atoi(force_coop) != 0 : (b.n <= 256 && max_q > 1024));
+    const long force_coop = opt.force_coop;
+    pl.coop = allow_coop && b.n * strips8 <= 2048 && (force_coop >= 0 ? force_coop != 0 : (b.n <= 256 && max_q > 1024));
     // A small batch of short queries is bound by the time of one step, not by throughput: 4 or 8 columns
     // per lane instead of 16 put more lanes of the wavefront to work and shorten the step.
     const bool narrow = !pl.coop && max_q <= 512 && b.n <= 4096;
@@ -188,7 +202,7 @@ Plan make_plan(const sa_align_batch& b) {
     pl.tpk_unit_words = (uint64_t)pl.t_pad * 64;
     const int sh = (b.type == SA_LOCAL) ? 6 : 0;
     const long em = ((long)b.match - b.gap) << sh, ex = ((long)b.mismatch - b.gap) << sh;
-    pl.tables = ex >= 0 && em <= 255 && !getenv("SA_NO_TABLES");
+    pl.tables = ex >= 0 && em <= 255 && !opt.no_tables;
     pl.entry_match = (uint32_t)em;
     pl.entry_mismatch = (uint32_t)(ex >= 0 ? ex : 0);
   } else {
@@ -268,6 +282,13 @@ __global__ __launch_bounds__(256) void cigar_stats_kernel(uint32_t n, const uint
       for (uint32_t op = 0; op < 4; ++op) op_len[4 * (uint64_t)p + op] = sum[op];
     }
   }
+}
+
+// Clears a few words (flags, counters) from the stream: a kernel, not hipMemsetAsync, so that a caller may
+// capture the batch call into a HIP graph.
+__global__ void clear_words(uint32_t* p, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
 }
 
 template <int MODE>
@@ -411,6 +432,23 @@ int sa_device_count(void) {
   return n;
 }
 
+int sa_set_option(const char* name, long value) {
+  if (!name) return fail(SA_ERR_ARGUMENT, "option name is NULL");
+  Options& o = options();
+  struct {
+    const char* name;
+    std::atomic<long>* slot;
+  } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
+               {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"pk16_k", &o.pk16_k},
+               {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices}};
+  for (auto& e : table)
+    if (!strcmp(name, e.name)) {
+      *e.slot = value;
+      return SA_OK;
+    }
+  return fail(SA_ERR_ARGUMENT, "unknown option '%s'", name);
+}
+
 const char* sa_device_arch(int device) {
   static thread_local char name[256];
   hipDeviceProp_t prop;
@@ -507,8 +545,9 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   if (pl.family == Family::LanePk16 && pl.tables) {
     // device-side decision, uniform for the call: at most four distinct symbols -> score tables
     alpha = (AlphabetInfo*)d_workspace;
-    SA_HIP_TRY(hipMemsetAsync(alpha, 0, sizeof(AlphabetInfo), stream));
+    static_assert(sizeof(AlphabetInfo) % 4 == 0 && sizeof(AlphabetInfo) <= 1024, "AlphabetInfo: one block of words");
     Timed tm(stream, 0);
+    hipLaunchKernelGGL(clear_words, dim3(1), dim3(256), 0, stream, (uint32_t*)alpha, (uint32_t)(sizeof(AlphabetInfo) / 4));
     hipLaunchKernelGGL(alphabet_scan, dim3(kScanBlocks), dim3(256), 0, stream, b->d_q, b->d_q_off, b->d_t,
                        b->d_t_off, b->n, alpha);
     hipLaunchKernelGGL(alphabet_table, dim3(1), dim3(256), 0, stream, alpha);

@@ -219,10 +219,11 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
         ldiag = recv;
         lastcol = left;
         if (MODE == SA_LOCAL) {
-          // first strict maximum in row-major order (src/alignment.cpp:203-207): a lane meets its rows
-          // in increasing order, so a later row must be strictly better
+          // first strict maximum in row-major order (src/alignment.cpp:203-207): inside a strip a lane
+          // meets its rows in increasing order, so a later row must be strictly better; a later strip
+          // (larger columns) revisits the rows from the top, and there an equal score in a smaller row wins
           const int rowbest = (int)(rowkey >> 4);
-          const bool better = rowbest > best;
+          const bool better = rowbest > best || (!COOP && rowbest == best && best > 0 && i < bi);
           best = better ? rowbest : best;
           bi = better ? i : bi;
           br = better ? c0 + 16 - (rowkey & 15u) : br;

@@ -159,12 +159,18 @@ void parallel_for(size_t n, size_t grain, unsigned threads, F f) {
   for (auto& t : th) t.join();
 }
 
+// Number of shards a host batch call deals its units to: one per GPU.  With the "fake_devices" option the
+// shards are that many, all of them run on GPU 0 side by side (own host thread, stream and buffers each),
+// which exercises the multi-GPU path on a one-GPU machine.
 int pick_devices(int requested) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return 0;
+  const long fake = options().fake_devices;
+  if (fake > 0) count = (int)std::min(fake, 64L);
   if (requested <= 0 || requested > count) return count;
   return requested;
 }
+int device_of_shard(int shard) { return options().fake_devices > 0 ? 0 : shard; }
 
 __global__ void gather_runs(const uint32_t* runs, const uint32_t* nruns, const uint64_t* out_off,
                             uint64_t stride, uint32_t n, uint32_t* out) {
@@ -275,7 +281,10 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   b.mismatch = mismatch;
   b.gap = gap;
   b.d_score = c.dev[SCORE].as<int32_t>();
-  b.d_target_begin = (target_begin || want_cigar) ? c.dev[TB].as<uint32_t>() : nullptr;
+  // Global / Semiglobal derive *target_begin from the CIGAR text; without a CIGAR the reference inspects an
+  // empty string and stores 1 (src/alignment.cpp:129-136, 342-348), and no traceback is needed
+  const bool tb_traced = target_begin && (want_cigar || type == SA_LOCAL);
+  b.d_target_begin = (tb_traced || want_cigar) ? c.dev[TB].as<uint32_t>() : nullptr;
   b.d_cigar_runs = want_cigar ? c.dev[RUNS].as<uint32_t>() : nullptr;
   b.d_cigar_nruns = want_cigar ? c.dev[NRUNS].as<uint32_t>() : nullptr;
   b.cigar_stride = stride;
@@ -305,7 +314,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   trace.mark("device done");
   for (size_t j = 0; j < n; ++j) {
     scores[idx[j]] = hscore[j];
-    if (target_begin) target_begin[idx[j]] = htb[j];
+    if (target_begin) target_begin[idx[j]] = tb_traced ? htb[j] : 1u;
   }
   trace.mark("scores scattered");
   if (want_cigar) {
@@ -428,16 +437,26 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   return SA_OK;
 }
 
-// Sorted split: units ordered by size (so that neighbouring lanes/waves see similar shapes), dealt to
-// the GPUs in blocks of `block` units round-robin, which also balances the total cost.
-std::vector<std::vector<uint32_t>> deal(const std::vector<uint64_t>& cost, int ndev, uint32_t block) {
-  std::vector<uint32_t> order(cost.size());
+// Sorted split: units ordered by decreasing `key` (so that neighbouring lanes / waves see similar shapes; left
+// in input order when all keys are equal), cut into blocks of `block` units, and every block given to the shard
+// with the smallest total `cost` so far (the first such shard): longest-processing-time-first over blocks.
+std::vector<std::vector<uint32_t>> deal(const std::vector<uint64_t>& key, const std::vector<uint64_t>& cost,
+                                        int ndev, uint32_t block) {
+  std::vector<uint32_t> order(key.size());
   std::iota(order.begin(), order.end(), 0u);
-  const bool uniform = std::all_of(cost.begin(), cost.end(), [&](uint64_t c) { return c == cost[0]; });
+  const bool uniform = std::all_of(key.begin(), key.end(), [&](uint64_t c) { return c == key[0]; });
   if (!uniform)
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] > key[b]; });
   std::vector<std::vector<uint32_t>> shards(ndev);
-  for (size_t i = 0; i < order.size(); ++i) shards[(i / block) % ndev].push_back(order[i]);
+  std::vector<long double> load(ndev, 0);
+  for (size_t b0 = 0; b0 < order.size(); b0 += block) {
+    const size_t b1 = std::min(order.size(), b0 + block);
+    long double c = 0;
+    for (size_t i = b0; i < b1; ++i) c += (long double)cost[order[i]];
+    const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    load[d] += c;
+    shards[d].insert(shards[d].end(), order.begin() + b0, order.begin() + b1);
+  }
   return shards;
 }
 
@@ -561,10 +580,12 @@ int align_batch_host(const char* const* queries, const uint32_t* query_lens,
   }
 
   for (const std::vector<uint32_t>& members : classes) {
-    std::vector<uint64_t> cost(members.size());
-    for (size_t i = 0; i < members.size(); ++i)  // order by target, then query length
-      cost[i] = ((uint64_t)target_lens[members[i]] << 32) | query_lens[members[i]];
-    auto shards = deal(cost, ndev, 1024);
+    std::vector<uint64_t> key(members.size()), cost(members.size());
+    for (size_t i = 0; i < members.size(); ++i) {  // order by target, then query length; balance by cells
+      key[i] = ((uint64_t)target_lens[members[i]] << 32) | query_lens[members[i]];
+      cost[i] = (uint64_t)target_lens[members[i]] * query_lens[members[i]];
+    }
+    auto shards = deal(key, cost, ndev, 1024);
     if (!in_order)  // class members -> pair numbers
       for (auto& sh : shards)
         for (uint32_t& x : sh) x = members[x];
@@ -582,7 +603,7 @@ int align_batch_host(const char* const* queries, const uint32_t* query_lens,
     }
     const unsigned threads = std::max(1u, host_threads() / (unsigned)(ndev * parts));
     const int rc = run_on_devices(ndev * parts, [&](int task) {
-      return align_shard(task / parts, shards[task], queries, query_lens, targets, target_lens, type, match,
+      return align_shard(device_of_shard(task / parts), shards[task], queries, query_lens, targets, target_lens, type, match,
                          mismatch, gap, scores, target_begin, cigars, threads, parts);
     });
     if (rc) return rc;
@@ -625,12 +646,32 @@ int sa_minimize_batch_host(const char* const* seqs, const uint32_t* lens, size_t
     if (ndev == 0) return fail(SA_ERR_NO_DEVICE, "no GPU visible (there is no CPU fallback)");
     std::vector<uint64_t> cost(n);
     for (size_t i = 0; i < n; ++i) cost[i] = lens[i];
-    const auto shards = deal(cost, ndev, 16);
+    const auto shards = deal(cost, cost, ndev, 16);
     const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
     return run_on_devices(ndev, [&](int d) {
-      return minimize_shard(d, shards[d], seqs, lens, k, w, variant, out_triples, out_counts, threads);
+      return minimize_shard(device_of_shard(d), shards[d], seqs, lens, k, w, variant, out_triples, out_counts, threads);
     });
   });
+}
+
+int sa_shard_units(const uint64_t* cost, size_t n, int n_shards, uint32_t block, uint32_t* shard_of,
+                   uint32_t* order) {
+  if (n_shards <= 0 || block == 0 || (n && (!cost || !shard_of)) || n > 0xFFFFFFF0ull)
+    return fail(SA_ERR_ARGUMENT, "sa_shard_units: bad argument");
+  try {
+    const std::vector<uint64_t> c(cost, cost + n);
+    const auto shards = deal(c, c, n_shards, block);
+    size_t at = 0;
+    for (int d = 0; d < n_shards; ++d)
+      for (uint32_t u : shards[d]) {
+        shard_of[u] = (uint32_t)d;
+        if (order) order[at] = u;
+        ++at;
+      }
+  } catch (const std::bad_alloc&) {
+    return fail(SA_ERR_MEMORY, "out of host memory");
+  }
+  return SA_OK;
 }
 
 int sa_remove_duplicate_host(uint32_t* triples, size_t n, uint32_t* out, size_t* out_n) {

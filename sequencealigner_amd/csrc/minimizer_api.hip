@@ -616,8 +616,8 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
   // enough chunks to occupy the GPU: 1024 windows each, 256 when the batch is small
   pl->chunk = (total_len / 1024 >= 65536) ? 1024 : 256;
-  if (const char* e = getenv("SA_MIN_CHUNK")) {  // test hook: any chunk length from 8 to 4096 windows
-    const long v = atol(e);
+  {  // test hook: any chunk length from 8 to 4096 windows
+    const long v = options().min_chunk;
     if (v >= 8 && v <= 4096) pl->chunk = (uint32_t)v;
   }
   pl->max_chunks = (uint32_t)(total_len / pl->chunk + n);

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -30,6 +31,22 @@ int fail(int code, const char* fmt, ...);
 enum : uint32_t { DIR_NONE = 0, DIR_DIAG = 1, DIR_LEFT = 2, DIR_UP = 3 };
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Process-wide tuning and test options behind sa_set_option().  Each starts from its SA_* environment
+// variable, read once when the first call needs it; later changes go through sa_set_option() only, so no
+// call reads the environment while another thread may be changing it.
+struct Options {
+  std::atomic<long> force_i32{0};     // SA_FORCE_I32: never use the packed 16-bit kernels
+  std::atomic<long> force_family{0};  // SA_FORCE_FAMILY: 0 automatic, 1 lane kernels, 2 wavefront kernels
+  std::atomic<long> force_coop{-1};   // SA_FORCE_COOP: -1 automatic, 0 / 1 pin the cooperative wavefront kernel
+  std::atomic<long> no_tables{0};     // SA_NO_TABLES: packed lane kernel without the score-table form
+  std::atomic<long> coop_c{0};        // SA_COOP_C: columns per lane of the cooperative kernel (0 automatic)
+  std::atomic<long> pk16_k{48};       // SA_PK16_K: rows per strip of the packed lane kernel (32, 48, 64)
+  std::atomic<long> min_chunk{0};     // SA_MIN_CHUNK: windows per minimizer chunk (0 automatic, 8..4096)
+  std::atomic<long> fake_devices{0};  // SA_FAKE_DEVICES: the host batch calls deal to this many shards, all of
+                                      // them on GPU 0 (exercises the multi-GPU path on one GPU)
+};
+Options& options();
 
 }  // namespace sa
 

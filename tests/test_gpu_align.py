@@ -38,21 +38,20 @@ def _grouped(cases):
 def _force_family(name):
     """Pins the kernel family the dispatcher may choose ("lane": the inter-pair lane kernels, packed
     16-bit where exact, else 32-bit; "wave": one pair per wavefront); None restores automatic choice."""
-    import os
-    os.environ.pop("SA_FORCE_FAMILY", None)
-    os.environ.pop("SA_FORCE_COOP", None)
-    os.environ.pop("SA_FORCE_I32", None)
+    from sequencealigner_amd import capi
+    family, coop, i32 = 0, -1, 0
     if name == "wave32":    # one wave per pair, 32-bit scores only
-        os.environ["SA_FORCE_I32"] = "1"
+        i32 = 1
         name = "wave"
     if name == "coop":      # wavefront kernels, one wave per (pair, strip) wherever the batch allows it
-        os.environ["SA_FORCE_FAMILY"] = "wave"
-        os.environ["SA_FORCE_COOP"] = "1"
+        family, coop = 2, 1
     elif name == "wave":    # wavefront kernels, one wave per pair
-        os.environ["SA_FORCE_FAMILY"] = "wave"
-        os.environ["SA_FORCE_COOP"] = "0"
-    elif name is not None:
-        os.environ["SA_FORCE_FAMILY"] = name
+        family, coop = 2, 0
+    elif name == "lane":
+        family = 1
+    capi.set_option("force_family", family)
+    capi.set_option("force_coop", coop)
+    capi.set_option("force_i32", i32)
 
 
 @pytest.fixture(params=["auto", "lane", "wave", "wave32", "coop"])
@@ -289,6 +288,47 @@ def test_long_gap_runs_vs_oracle(oracle, wave_mode):
     pairs.append(("T" * 700 + "ACGTACGTAC" + "G" * 900, "ACGTACGTAC"))
     for typ, (m, x, g) in ((0, (1, -1, -1)), (2, (1, -1, -1)), (1, (2, -3, -1)), (0, (2, -2, 0)), (1, (1, -1, 0))):
         _run_group(_oracle_cases(oracle, pairs, typ, m, x, g))
+
+
+def test_local_ties_across_strips_vs_oracle(oracle):
+    """Local's end cell is the first strict maximum in row-major order (src/alignment.cpp:203-207).  A
+    wavefront that walks the strips of its pair one after the other meets the rows of a later strip (larger
+    columns) after ALL rows of the earlier one: an equal score in a smaller row of a later strip must win.
+    Directed: score 5 ends at (row 50, column 10) and at (row 20, column 1030), both in lane 0 of their
+    strips; the alignment must be the one in row 20.  Then many tie-prone pairs over a two-letter alphabet."""
+    from sequencealigner_amd import align, synth
+    q = bytearray(b"A" * 2048)
+    t = bytearray(b"C" * 300)
+    q[5:10] = b"GGGGG"
+    t[45:50] = b"GGGGG"
+    q[1025:1030] = b"TTTTT"
+    t[15:20] = b"TTTTT"
+    want = oracle.align(bytes(q), bytes(t), 1, 1, -1, -1)
+    assert want == (5, "5M", 15)
+    for fam in ("wave", "wave32", "coop", "lane", None):
+        _force_family(fam)
+        try:
+            s, c, tb = align.align_batch([bytes(q)], [bytes(t)], 1, 1, -1, -1)
+            assert (int(s[0]), c[0], int(tb[0])) == want, fam
+        finally:
+            _force_family(None)
+    rng = np.random.default_rng(808)
+    two = np.frombuffer(b"AC", dtype=np.uint8)
+    qs = [two[rng.integers(0, 2, size=int(rng.integers(1500, 2500)))] for _ in range(300)]
+    ts = [two[rng.integers(0, 2, size=int(rng.integers(1500, 2500)))] for _ in range(300)]
+    qb, qo = synth.to_blob(qs)
+    tb_, to = synth.to_blob(ts)
+    for (m, x, g) in ((1, -1, -1), (1, -3, -3), (2, -1, -2)):
+        b = align.DeviceAlignBatch(qs, ts, 1, m, x, g)
+        assert b.kernel_name() == "wave_i32"
+        b.run()
+        import torch
+        torch.cuda.synchronize()
+        s, tbeg = oracle.align_batch(qb, qo, tb_, to, 1, m, x, g, True, 16)
+        assert np.array_equal(b.scores(), s)
+        assert np.array_equal(b.target_begins(), tbeg)      # the start row depends on the end cell chosen
+        for i in range(0, 300, 29):
+            assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), 1, m, x, g)[1]
 
 
 def test_cooperative_single_long_pair_vs_oracle(oracle):

@@ -139,3 +139,71 @@ def test_align_batch_host_with_outliers(oracle):
             if typ == 2 and want[0] <= 0:
                 continue
             assert (scores[i], got_c, tb[i]) == want, (i, typ)
+
+
+@pytest.fixture
+def four_shards():
+    """The host batch calls deal their units to 4 shards that all run on GPU 0 at the same time, each on its
+    own host thread, stream and buffers: the multi-GPU path of the device batch queue on a one-GPU box."""
+    from sequencealigner_amd import capi
+    capi.set_option("fake_devices", 4)
+    yield 4
+    capi.set_option("fake_devices", 0)
+
+
+def test_align_batch_host_over_several_shards(oracle, four_shards):
+    from sequencealigner_amd import capi, synth
+    lib = capi.lib()
+    assert lib.sa_device_count() >= 1
+    rng = np.random.default_rng(33)
+    qs, ts = [], []
+    for i in range(6000):
+        T = int(rng.integers(30, 700)) if i % 50 else int(rng.integers(1500, 2600))
+        t = bytes(synth.random_bases(rng, T))
+        a = int(rng.integers(0, T // 2))
+        q = bytes(synth.substitute(rng, np.frombuffer(t[a:a + int(rng.integers(10, T - a + 1))], np.uint8), 0.06))
+        qs.append(q)
+        ts.append(t)
+    n = len(qs)
+    qb, qo = synth.to_blob(qs)
+    tbb, to = synth.to_blob(ts)
+    for typ, (m, x, g) in ((0, (1, -1, -1)), (1, (2, -3, -2)), (2, (1, -1, -1))):
+        qa, ql = _c_strings(qs)
+        ta, tl = _c_strings(ts)
+        scores = (C.c_int32 * n)()
+        tb = (C.c_uint32 * n)()
+        cig = (C.c_void_p * n)()
+        capi.check(lib.sa_align_batch_host(qa, ql, ta, tl, n, typ, m, x, g, 0, scores, tb, cig))
+        want_s, want_tb = oracle.align_batch(qb, qo, tbb, to, typ, m, x, g, True, 16)
+        ok = np.ones(n, bool) if typ == 0 else want_s > 0   # the reference's defined envelope
+        assert np.array_equal(np.ctypeslib.as_array(scores)[ok], want_s[ok]), typ
+        assert np.array_equal(np.ctypeslib.as_array(tb)[ok], want_tb[ok]), typ
+        for i in range(n):
+            if i % 23 == 0 and ok[i]:
+                assert C.cast(cig[i], C.c_char_p).value.decode() == oracle.align(qs[i], ts[i], typ, m, x, g)[1], i
+            lib.sa_free(cig[i])
+        # without CIGAR strings: Local still reports the start row, Global / Semiglobal report 1
+        tb2 = (C.c_uint32 * n)()
+        capi.check(lib.sa_align_batch_host(qa, ql, ta, tl, n, typ, m, x, g, 3, scores, tb2, None))
+        assert np.array_equal(np.ctypeslib.as_array(scores)[ok], want_s[ok]), typ
+        if typ == 1:
+            assert np.array_equal(np.ctypeslib.as_array(tb2)[ok], want_tb[ok])
+        else:
+            assert (np.ctypeslib.as_array(tb2) == 1).all()
+
+
+def test_minimize_batch_host_over_several_shards(oracle, four_shards):
+    from sequencealigner_amd import capi, synth
+    lib = capi.lib()
+    rng = np.random.default_rng(5)
+    seqs = [bytes(synth.genome(int(L), seed=300 + i))
+            for i, L in enumerate(rng.integers(19, 20_000, size=700).tolist() + [150_000, 19])]
+    n = len(seqs)
+    sa, sl = _c_strings(seqs)
+    outs = (C.c_void_p * n)()
+    counts = (C.c_uint64 * n)()
+    capi.check(lib.sa_minimize_batch_host(sa, sl, n, 15, 5, capi.SA_MIN_BINARY, 0, outs, counts))
+    for i in range(n):
+        got = np.ctypeslib.as_array(C.cast(outs[i], C.POINTER(C.c_uint32)), shape=(counts[i], 3)).copy()
+        lib.sa_free(outs[i])
+        assert np.array_equal(got, oracle.minimize_binary_array(seqs[i], 15, 5)), i

@@ -101,12 +101,19 @@ def test_sortedness_and_uniqueness_property():
 
 
 @pytest.mark.parametrize("chunk", ["24", "64", "1024"])
-def test_mixed_lengths_and_chunk_sizes_vs_oracle(oracle, chunk, monkeypatch):
+def test_mixed_lengths_and_chunk_sizes_vs_oracle(oracle, chunk):
     """Sequences with more keys than the in-LDS sort takes (left to the segmented sort) next to short
     ones, constant and periodic stretches that keep the candidate sets from collapsing, and chunk
     lengths below / equal to / above the warm-up length."""
-    from sequencealigner_amd import minimize, synth
-    monkeypatch.setenv("SA_MIN_CHUNK", chunk)
+    from sequencealigner_amd import capi, minimize, synth
+    capi.set_option("min_chunk", int(chunk))
+    try:
+        _mixed_lengths(oracle, chunk, minimize, synth)
+    finally:
+        capi.set_option("min_chunk", 0)
+
+
+def _mixed_lengths(oracle, chunk, minimize, synth):
     rng = random.Random(5)
     seqs = [bytes(synth.genome(40_000, seed=81)),
             bytes(synth.genome(3_000, seed=82)) + b"A" * 5000 + bytes(synth.genome(9_000, seed=83)) + b"CG" * 3000,

@@ -132,3 +132,63 @@ def test_failed_host_call_hands_nothing_out():
     rc = lib.sa_minimize_batch_host(None, lens, n, 15, 5, 0, 0, out, counts)
     assert rc == capi.SA_ERR_ARGUMENT
     assert [out[i] for i in range(n)] == [None] * n
+
+
+def _shard_units(cost, n_shards, block):
+    import ctypes as C
+    from sequencealigner_amd import capi
+    cost = np.ascontiguousarray(cost, dtype=np.uint64)
+    shard_of = np.full(cost.size, 0xFFFFFFFF, dtype=np.uint32)
+    order = np.full(cost.size, 0xFFFFFFFF, dtype=np.uint32)
+    capi.check(capi.lib().sa_shard_units(cost.ctypes.data, cost.size, n_shards, block, shard_of.ctypes.data,
+                                         order.ctypes.data))
+    return shard_of, order
+
+
+def test_device_batch_queue_dealing_rule():
+    """sa_shard_units is the rule by which sa_align_batch_host / sa_minimize_batch_host split a batch over the
+    GPUs (the replacement of the reference's per-read Submit loop, src/mapper.cpp:665-675): a partition of the
+    units, balanced by cost, every shard in decreasing cost order; equal costs keep the input order."""
+    rng = np.random.default_rng(3)
+    cost = (rng.integers(50, 3000, size=20_000) * rng.integers(50, 3000, size=20_000)).astype(np.uint64)
+    for n_shards, block in ((1, 16), (2, 16), (4, 1024), (8, 16), (8, 1)):
+        shard_of, order = _shard_units(cost, n_shards, block)
+        assert shard_of.max() == n_shards - 1
+        assert np.array_equal(np.sort(order), np.arange(cost.size))          # a partition, every unit once
+        loads = np.bincount(shard_of, weights=cost.astype(np.float64), minlength=n_shards)
+        assert loads.max() / loads.mean() < (1.01 if block <= 16 else 1.06)
+        at = 0
+        for d in range(n_shards):                                            # order lists shard after shard
+            members = order[at:at + int((shard_of == d).sum())]
+            at += members.size
+            assert (shard_of[members] == d).all()
+            assert (np.diff(cost[members].astype(np.int64)) <= 0).all()      # decreasing cost inside a shard
+    # equal costs: no sort, blocks of `block` consecutive units, round-robin
+    shard_of, order = _shard_units(np.full(10, 7), 3, 2)
+    assert shard_of.tolist() == [0, 0, 1, 1, 2, 2, 0, 0, 1, 1]
+    assert order.tolist() == [0, 1, 6, 7, 2, 3, 8, 9, 4, 5]
+    # fewer units than shards, no units, bad arguments
+    assert _shard_units([5, 9], 4, 16)[0].tolist() == [0, 0]
+    assert _shard_units([], 4, 16)[0].size == 0
+    from sequencealigner_amd import capi
+    assert capi.lib().sa_shard_units(None, 0, 0, 16, None, None) == capi.SA_ERR_ARGUMENT
+
+
+def test_options_are_set_by_name_only():
+    from sequencealigner_amd import capi
+    lib = capi.lib()
+    assert lib.sa_set_option(b"no_such_option", 1) == capi.SA_ERR_ARGUMENT
+    assert b"unknown option" in lib.sa_last_error()
+    import ctypes
+    b = capi.AlignBatch()
+    b.n, b.max_qlen, b.max_tlen, b.min_qlen, b.min_tlen = 1_000_000, 150, 300, 150, 300
+    b.type, b.match, b.mismatch, b.gap = 1, 1, -1, -1
+    try:
+        capi.set_option("force_i32", 1)
+        assert lib.sa_align_kernel_name(ctypes.byref(b)) == b"lane_i32"
+        capi.set_option("force_family", 2)
+        assert lib.sa_align_kernel_name(ctypes.byref(b)) == b"wave_i32"
+    finally:
+        capi.set_option("force_i32", 0)
+        capi.set_option("force_family", 0)
+    assert lib.sa_align_kernel_name(ctypes.byref(b)) == b"lane_pk16"

@@ -1,9 +1,9 @@
 """Times Global batches of several shapes with the kernel family chosen by the dispatcher and with each
-family forced (SA_FORCE_FAMILY is read per call), to check the dispatcher's rate estimates."""
+family forced (sa_set_option), to check the dispatcher's rate estimates."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from sequencealigner_amd import align, synth
+from sequencealigner_amd import align, capi, synth
 
 def run(q, t, typ):
     b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1)
@@ -25,9 +25,8 @@ for n, L in ((400_000, 200), (200_000, 300), (60_000, 600), (20_000, 1000), (100
     for typ in (0, 1):
         line = "n=%d %dx%d type %d:" % (n, L, L, typ)
         for fam in (None, "lane", "wave"):
-            if fam: os.environ["SA_FORCE_FAMILY"] = fam
-            else: os.environ.pop("SA_FORCE_FAMILY", None)
+            capi.set_option("force_family", {None: 0, "lane": 1, "wave": 2}[fam])
             name, dt, cells = run(q, t, typ)
             line += "  %s %s %.2f ms %.0f GCUPS" % (fam or "auto", name, dt * 1e3, cells / dt / 1e9)
-        os.environ.pop("SA_FORCE_FAMILY", None)
+        capi.set_option("force_family", 0)
         print(line, flush=True)

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import cpu_checker  # noqa: E402
-from sequencealigner_amd import align  # noqa: E402
+from sequencealigner_amd import align, capi  # noqa: E402
 
 EDGES = [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 256,
          257, 300, 511, 512, 513, 1023, 1024, 1025, 1500, 2047, 2048, 2049]
@@ -37,16 +37,9 @@ def main():
     batches = pairs_checked = 0
     while time.time() < t_end:
         fam = rng.choice([None, "lane", "wave", "wave32", "coop"])
-        for k in ("SA_FORCE_FAMILY", "SA_FORCE_COOP", "SA_FORCE_I32"):
-            os.environ.pop(k, None)
-        if fam == "wave32":
-            os.environ["SA_FORCE_I32"] = "1"
-            os.environ["SA_FORCE_FAMILY"] = "wave"
-        elif fam == "coop":
-            os.environ["SA_FORCE_FAMILY"] = "wave"
-            os.environ["SA_FORCE_COOP"] = "1"
-        elif fam:
-            os.environ["SA_FORCE_FAMILY"] = fam
+        capi.set_option("force_i32", 1 if fam == "wave32" else 0)
+        capi.set_option("force_family", {None: 0, "lane": 1}.get(fam, 2))
+        capi.set_option("force_coop", 1 if fam == "coop" else 0 if fam in ("wave", "wave32") else -1)
         typ = rng.choice([0, 1, 2])
         match, mismatch, gap = rng.choice([0, 1, 1, 2, 3]), rng.choice([-3, -2, -1, -1, 0, 1]), rng.choice([-3, -2, -1, -1, 0, 1])
         big = rng.random() < 0.15
