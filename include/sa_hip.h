@@ -128,6 +128,21 @@ size_t sa_align_workspace_bytes(const sa_align_batch* batch, size_t* min_bytes);
 int sa_align_batch_device(int device, void* stream, const sa_align_batch* batch, void* d_workspace,
                           size_t workspace_bytes);
 
+/* sa_align_batch_device without a workspace argument and without any allocation.  This entry point has no
+ * counterpart in the reference; it is for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The scratch memory (direction bits, strip
+ * boundary rows, repacked sequences, per-pair end cells) is an array of sa_align_static_scratch_bytes() bytes
+ * (64 MiB) that is part of the library's code object: every GPU the library runs on holds its own copy from
+ * the first call on that GPU until the process ends.  Same inputs, outputs and results as
+ * sa_align_batch_device; a batch larger than one pass of the array is processed in several passes.  The call
+ * only enqueues kernels on `stream`: it never allocates, frees or synchronises, and never picks the cooperative
+ * kernels (which synchronise).  A batch whose single pass does not fit (for example pairs beyond about
+ * 10 kbp x 11 kbp) is rejected with SA_ERR_WORKSPACE.  All calls on one GPU share that GPU's array: calls
+ * that overlap in time on one GPU (different streams or host threads) race and must be serialised by the
+ * caller.  sa_align_profile() must be off (its timing events are allocations). */
+size_t sa_align_static_scratch_bytes(void);
+int sa_align_batch_device_static(int device, void* stream, const sa_align_batch* batch);
+
 /* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32", "wave_i32",
  * "wave_i32_coop"), for logs and profiles. */
 const char* sa_align_kernel_name(const sa_align_batch* batch);

@@ -124,6 +124,13 @@ class DeviceAlignBatch:
                                                   C.byref(self.batch), C.c_void_p(self.d_ws.data_ptr()),
                                                   self.workspace_bytes))
 
+    def run_static(self, stream=None):
+        """The same batch through sa_align_batch_device_static: the library's own static scratch array takes
+        the place of the workspace and nothing is allocated."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        capi.check(self.lib.sa_align_batch_device_static(self.dev_index, C.c_void_p(s.cuda_stream),
+                                                         C.byref(self.batch)))
+
     def scores(self):
         return self.d_score[:self.n].cpu().numpy()
 

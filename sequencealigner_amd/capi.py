@@ -66,6 +66,8 @@ SYMBOLS = [
     ("sa_align_workspace_bytes", C.c_size_t, [C.POINTER(AlignBatch), C.POINTER(C.c_size_t)]),
     ("sa_align_batch_device", C.c_int,
      [C.c_int, C.c_void_p, C.POINTER(AlignBatch), C.c_void_p, C.c_size_t]),
+    ("sa_align_static_scratch_bytes", C.c_size_t, []),
+    ("sa_align_batch_device_static", C.c_int, [C.c_int, C.c_void_p, C.POINTER(AlignBatch)]),
     ("sa_align_kernel_name", C.c_char_p, [C.POINTER(AlignBatch)]),
     ("sa_align_profile", C.c_int, [C.c_int]),
     ("sa_align_profile_read", C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

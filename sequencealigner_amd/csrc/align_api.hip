@@ -509,8 +509,61 @@ const char* sa_align_kernel_name(const sa_align_batch* b) {
   return make_plan(*b).name;
 }
 
+}  // extern "C"
+
+namespace sa {
+namespace {
+
+// The scratch memory of sa_align_batch_device_static: one array per GPU, part of the library's code object,
+// so it exists from the moment the library is loaded on a GPU until the process ends and no call ever
+// allocates it.  In host code the array's name is only a handle for hipGetSymbolAddress; g_scratch_ptr[device]
+// holds the array's address on that GPU.
+constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on `device`, which must be the current device; looked up once per device.
+int static_scratch(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) return fail(SA_ERR_ARGUMENT, "device %d out of range", device);
+  std::lock_guard<std::mutex> g(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    SA_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(SA_ERR_HIP, "hipGetSymbolAddress gave no address for the static scratch array");
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return SA_OK;
+}
+
+int align_batch_device(int device, void* stream_, const sa_align_batch* b, void* d_workspace, size_t workspace_bytes,
+                       bool static_scratch_call);
+
+}  // namespace
+}  // namespace sa
+
+extern "C" {
+
 int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, void* d_workspace,
                           size_t workspace_bytes) {
+  return align_batch_device(device, stream_, b, d_workspace, workspace_bytes, false);
+}
+
+size_t sa_align_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int sa_align_batch_device_static(int device, void* stream, const sa_align_batch* b) {
+  return align_batch_device(device, stream, b, nullptr, 0, true);
+}
+
+}  // extern "C"
+
+namespace sa {
+namespace {
+
+int align_batch_device(int device, void* stream_, const sa_align_batch* b, void* d_workspace, size_t workspace_bytes,
+                       bool static_scratch_call) {
   if (!b) return fail(SA_ERR_ARGUMENT, "batch is NULL");
   if (b->type < 0 || b->type > 2) return fail(SA_ERR_ARGUMENT, "unknown alignment type %d", b->type);
   if (b->n == 0) return SA_OK;
@@ -525,7 +578,17 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   SA_HIP_TRY(hipSetDevice(device));
   hipStream_t stream = (hipStream_t)stream_;
 
-  const Plan pl = make_plan(*b);
+  // the static-scratch call only enqueues work: never the cooperative kernels, which synchronise the stream
+  const Plan pl = make_plan(*b, !static_scratch_call);
+  if (static_scratch_call) {
+    if (pl.bytes_per_block + kFixedWorkspace > kStaticScratchBytes)
+      return fail(SA_ERR_WORKSPACE,
+                  "sa_align_batch_device_static: one pass of this batch (%s, query <= %u, target <= %u) needs %zu "
+                  "bytes of scratch, the static array holds %zu; use sa_align_batch_device with a workspace",
+                  pl.name, b->max_qlen, b->max_tlen, pl.bytes_per_block + kFixedWorkspace, kStaticScratchBytes);
+    if (int rc = static_scratch(device, &d_workspace)) return rc;
+    workspace_bytes = kStaticScratchBytes;
+  }
   if (!d_workspace || workspace_bytes < pl.bytes_per_block + kFixedWorkspace)
     return fail(SA_ERR_WORKSPACE, "workspace of %zu bytes is below the minimum %zu", workspace_bytes,
                 pl.bytes_per_block + kFixedWorkspace);
@@ -619,4 +682,5 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
   return SA_OK;
 }
 
-}  // extern "C"
+}  // namespace
+}  // namespace sa

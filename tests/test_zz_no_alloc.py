@@ -1,0 +1,75 @@
+"""GPU test of sa_align_batch_device_static, the alignment batch call that allocates nothing (its scratch
+memory is a static array inside the library): same scores, target_begin and CIGAR runs as
+sa_align_batch_device, on consecutive calls that share the array, the later ones with smaller inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _outputs(b):
+    import torch
+    torch.cuda.synchronize()
+    runs = b.d_runs.cpu().numpy().view(np.uint32).reshape(b.n, b.stride)
+    nruns = b.d_nruns[:b.n].cpu().numpy()
+    valid = np.arange(b.stride)[None, :] >= (b.stride - nruns)[:, None]
+    return b.scores().copy(), b.target_begins().copy(), nruns.copy(), np.where(valid, runs, 0)
+
+
+def _both_ways(b):
+    """Runs the batch through the workspace entry point, clears the outputs, runs it through the static
+    entry point and returns both sets of outputs."""
+    b.run()
+    want = _outputs(b)
+    for t in (b.d_score, b.d_tb, b.d_runs, b.d_nruns):
+        t.fill_(-1)
+    b.run_static()
+    return want, _outputs(b)
+
+
+def test_static_scratch_entry_point_equals_workspace_entry_point(oracle):
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    lib = capi.lib()
+    scratch = lib.sa_align_static_scratch_bytes()
+    assert scratch == 64 << 20
+    # call 1: 12 000 Local pairs of the benchmark shape - the packed lane kernel, more than one pass of the array
+    q, t = synth.pairs_short_read_window(12_000, seed=31)
+    big = align.DeviceAlignBatch(q, t, 1, 1, -1, -1, workspace_bytes=1 << 30)
+    assert big.kernel_name() == "lane_pk16"
+    mn = C.c_size_t(0)
+    assert lib.sa_align_workspace_bytes(C.byref(big.batch), C.byref(mn)) > scratch > mn.value
+    want, got = _both_ways(big)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    for i in range(0, 12_000, 1201):   # and the workspace path is itself checked against the CPU checker
+        assert (int(want[0][i]), big.cigars([i])[0], int(want[1][i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
+    # call 2, right after it on the same array, smaller: 60 Global pairs on the packed wavefront kernel
+    q2, t2 = synth.pairs_global_1k(60, seed=32, length=700)
+    small = align.DeviceAlignBatch(q2, t2[:, :650], 0, 1, -1, -1)
+    assert small.kernel_name() == "wave_pk16"
+    want, got = _both_ways(small)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    # call 3: 9 ragged Semiglobal pairs with a scoring the packed kernels do not take (32-bit kernels), then
+    # call 1's batch again: nothing of the smaller calls may be left behind in the array
+    rng = np.random.default_rng(5)
+    qs = [synth.random_bases(rng, int(n)) for n in rng.integers(5, 900, size=9)]
+    ts = [np.concatenate([synth.random_bases(rng, 30), x, synth.random_bases(rng, 20)]) for x in qs]
+    odd = align.DeviceAlignBatch(qs, ts, 2, 3, 1, 2)
+    assert "pk16" not in odd.kernel_name()
+    want, got = _both_ways(odd)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    want, got = _both_ways(big)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    # a batch whose single pass exceeds the array is refused with a clear error, nothing is launched
+    qq, tt = synth.pair_global_long(20_000, seed=3)
+    huge = align.DeviceAlignBatch([qq], [tt], 0, 1, -1, -1, workspace_bytes=1)
+    rc = lib.sa_align_batch_device_static(0, None, C.byref(huge.batch))
+    assert rc == capi.SA_ERR_WORKSPACE
+    assert b"static array holds" in lib.sa_last_error()
+    torch.cuda.synchronize()
