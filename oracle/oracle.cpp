@@ -178,6 +178,48 @@ AlignOut align_full(const char* q, uint32_t Q, const char* t, uint32_t T, int mo
   return out;
 }
 
+// The score alone in linear memory: the same borders, recurrence and end-cell rules as align_full
+// (alignment.cpp:46-52, 60-95, 152-209, 263-308), but only two rows of the matrix are kept, so pairs far
+// beyond what the 8-byte-per-cell matrix allows (100 kbp x 100 kbp = 80 GB) can be scored on the CPU.
+// Checked against the compiled reference on pairs up to 5 kbp (tests/test_oracle_vs_reference.py).
+int score_linear(const char* q, uint32_t Q, const char* t, uint32_t T, int mode, int match, int mismatch,
+                 int gap) {
+  const bool local_zero = (mode == 1 && gap < 0);
+  std::vector<int32_t> prev((size_t)Q + 1), cur((size_t)Q + 1), tmp((size_t)Q + 1);
+  prev[0] = 0;
+  for (uint32_t r = 1; r <= Q; ++r) prev[r] = local_zero ? 0 : gap * (int)r;
+  int best = 0;
+  int best_last = 0;  // Semiglobal: first strict maximum > 0 of the last column; H[0][Q] without one
+  bool have_last = false;
+  for (uint32_t i = 1; i <= T; ++i) {
+    cur[0] = (mode == 0 || (mode == 1 && !local_zero)) ? gap * (int)i : 0;
+    const char ti = t[i - 1];
+    // max(diag, up) has no dependency along the row (the compiler vectorises this loop) ...
+    for (uint32_t r = 1; r <= Q; ++r)
+      tmp[r] = std::max(prev[r - 1] + (ti == q[r - 1] ? match : mismatch), prev[r] + gap);
+    // ... the left candidate is the sequential part
+    int left = cur[0];
+    if (mode == 1) {
+      for (uint32_t r = 1; r <= Q; ++r) {
+        int m = std::max(tmp[r], left + gap);
+        if (m > best) best = m;  // alignment.cpp:203-207 (the score of the first strict maximum is the maximum)
+        if (m <= 0) m = 0;       // alignment.cpp:190-192
+        cur[r] = left = m;
+      }
+    } else {
+      for (uint32_t r = 1; r <= Q; ++r) cur[r] = left = std::max(tmp[r], left + gap);
+      if (mode == 2 && cur[Q] > best_last) {  // alignment.cpp:87-92
+        best_last = cur[Q];
+        have_last = true;
+      }
+    }
+    prev.swap(cur);
+  }
+  if (mode == 0) return prev[Q];
+  if (mode == 1) return best;
+  return have_last ? best_last : (local_zero ? 0 : gap * (int)Q);  // row 0 when nothing is positive (as align_full)
+}
+
 // ---- minimizers ------------------------------------------------------------------------------
 
 // minimizer_binary.cpp:13-50.  forward: C0 A1 T2 G3; other strand: 3 - forward; else -1.
@@ -403,6 +445,22 @@ int sa_cpu_align(const char* query, uint32_t query_len, const char* target, uint
   }
   if (target_begin) *target_begin = r.target_begin;
   return r.score;
+}
+
+int sa_cpu_score_linear(const char* query, uint32_t query_len, const char* target, uint32_t target_len,
+                        int type, int match, int mismatch, int gap) {
+  if (type < 0 || type > 2) return 9999;
+  return score_linear(query, query_len, target, target_len, type, match, mismatch, gap);
+}
+
+int sa_cpu_score_linear_batch(const char* q_blob, const uint64_t* q_off, const char* t_blob,
+                              const uint64_t* t_off, size_t n, int type, int match, int mismatch, int gap,
+                              int threads, int32_t* scores) {
+  task_farm(n, threads, [&](size_t i) {
+    scores[i] = sa_cpu_score_linear(q_blob + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), t_blob + t_off[i],
+                                    (uint32_t)(t_off[i + 1] - t_off[i]), type, match, mismatch, gap);
+  });
+  return 0;
 }
 
 size_t sa_cpu_minimize_binary(const char* sequence, uint32_t sequence_len, uint32_t kmer_len,

@@ -31,6 +31,18 @@ int sa_cpu_align(const char* query, uint32_t query_len, const char* target, uint
                  int type, int match, int mismatch, int gap,
                  char* cigar_buf, size_t cigar_cap, size_t* cigar_len, uint32_t* target_begin);
 
+/* The alignment score alone, computed in linear memory (two rows of the matrix): same value as
+ * sa_cpu_align returns, for pairs whose full matrix would not fit in host memory.  Only the restatement
+ * library has it (the reference has no such function); it is checked against the compiled reference's
+ * Align() on pairs of up to 5 kbp. */
+int sa_cpu_score_linear(const char* query, uint32_t query_len, const char* target, uint32_t target_len,
+                        int type, int match, int mismatch, int gap);
+
+/* sa_cpu_score_linear over n independent pairs (blobs + n+1 offsets) on `threads` std::threads. Returns 0. */
+int sa_cpu_score_linear_batch(const char* q_blob, const uint64_t* q_off, const char* t_blob,
+                              const uint64_t* t_off, size_t n, int type, int match, int mismatch, int gap,
+                              int threads, int32_t* scores);
+
 /* MinimizeBinary (reference src/minimizer_binary.cpp:136-178).  sequence must be NUL-terminated.
  * Writes up to cap triples (value, position, strand) to out; returns the number of minimizers. */
 size_t sa_cpu_minimize_binary(const char* sequence, uint32_t sequence_len, uint32_t kmer_len,

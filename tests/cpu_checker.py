@@ -33,6 +33,13 @@ class CpuChecker:
         L.sa_cpu_minimize_batch.restype = C.c_int
         L.sa_cpu_minimize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        if hasattr(L, "sa_cpu_score_linear"):
+            L.sa_cpu_score_linear.restype = C.c_int
+            L.sa_cpu_score_linear.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int,
+                                              C.c_int, C.c_int]
+            L.sa_cpu_score_linear_batch.restype = C.c_int
+            L.sa_cpu_score_linear_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         if hasattr(L, "sa_cpu_cigar_block_match"):
             L.sa_cpu_cigar_block_match.restype = None
             L.sa_cpu_cigar_block_match.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -61,6 +68,22 @@ class CpuChecker:
                                       C.byref(tb) if want_target_begin else None)
         return (score, buf.value.decode() if want_cigar else None,
                 tb.value if want_target_begin else None)
+
+    def score_linear(self, query, target, type_, match, mismatch, gap):
+        """The score alone, in linear memory (restatement library only)."""
+        q = query if isinstance(query, bytes) else query.encode()
+        t = target if isinstance(target, bytes) else target.encode()
+        return self.lib.sa_cpu_score_linear(q, len(q), t, len(t), type_, match, mismatch, gap)
+
+    def score_linear_batch(self, q_blob, q_off, t_blob, t_off, type_, match, mismatch, gap, threads):
+        n = len(q_off) - 1
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        scores = np.zeros(n, dtype=np.int32)
+        self.lib.sa_cpu_score_linear_batch(q_blob.ctypes.data, q_off.ctypes.data, t_blob.ctypes.data,
+                                           t_off.ctypes.data, n, type_, match, mismatch, gap, threads,
+                                           scores.ctypes.data)
+        return scores
 
     def _minimize(self, fn, seq, k, w):
         s = seq if isinstance(seq, bytes) else seq.encode()

@@ -83,3 +83,53 @@ def test_batch_entry_points_agree(oracle, reference_lib):
     for i in range(8):
         one = oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
         assert one[0] == s1[i] and one[2] == b1[i]
+
+
+def test_linear_memory_scorer_differential(oracle, reference_lib):
+    """The two-row scorer (used to check pairs whose full matrix does not fit in host memory) returns the
+    score of the compiled reference's Align(): small pairs over every scheme and mode, then pairs of up to
+    5 kbp of the benchmark generators."""
+    rng = random.Random(79)
+    n = 0
+    for _ in range(600):
+        alpha = rng.choice(["ACGT", "AC", "ACGTN", "A"])
+        t = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 90)))
+        if rng.random() < 0.5:
+            cut = t[rng.randint(0, len(t) // 2):]
+            q = "".join(c if rng.random() > 0.15 else rng.choice(alpha) for c in cut) or "A"
+        else:
+            q = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 90)))
+        for m, x, g in SCHEMES:
+            for typ in (0, 1, 2):
+                got = oracle.score_linear(q, t, typ, m, x, g)
+                assert got == oracle.align(q, t, typ, m, x, g)[0]
+                if typ != 0 and got <= 0:
+                    continue   # outside the reference's defined behaviour (uninitialised end cell: it may crash)
+                want = reference_lib.align(q, t, typ, m, x, g, want_cigar=False, want_target_begin=False)[0]
+                assert got == want, (q, t, typ, m, x, g)
+                n += 1
+    assert n > 9000
+    qq, tt = synth.pair_global_long(5000, seed=12)
+    qs, ts = synth.pairs_semiglobal_long(2, seed=13, read_len=3000, window_len=3300, lead=150)
+    for q, t in ((bytes(qq), bytes(tt[:4700])), (bytes(qs[0]), bytes(ts[0])), (bytes(qs[1]), bytes(ts[1]))):
+        for typ, (m, x, g) in ((0, (1, -1, -1)), (2, (1, -1, -1)), (1, (2, -3, -2)), (0, (1, -1, 0))):
+            want = reference_lib.align(q, t, typ, m, x, g, want_cigar=False, want_target_begin=False)[0]
+            assert oracle.score_linear(q, t, typ, m, x, g) == want
+
+
+def test_minimize_binary_k_above_16_differential(oracle, reference_lib):
+    """k > 16: the reference's 32-bit k-mer values wrap (src/minimizer_binary.cpp:53-78: the shifts drop the
+    high bits, getMask saturates at 0xFFFFFFFF), so a value is the last 16 bases of the k-mer, while positions,
+    the expiry rule and the window count still use k.  The restatement must follow the compiled reference."""
+    rng = random.Random(80)
+    for _ in range(1200):
+        k = rng.randint(17, 31)
+        w = rng.randint(1, min(k + 1, 24))
+        L = rng.randint(k + w - 1, k + w - 1 + rng.choice([0, 1, 5, 50, 400]))
+        alpha = rng.choice(["ACGT", "acgt", "AC", "A", "ACGTacgt", "ACGTN", "ACGT" * 10 + "N"])
+        if rng.random() < 0.3:
+            unit = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 6)))
+            s = (unit * (L // len(unit) + 1))[:L]
+        else:
+            s = "".join(rng.choice(alpha) for _ in range(L))
+        assert oracle.minimize_binary(s, k, w) == reference_lib.minimize_binary(s, k, w), (s, k, w)
