@@ -4,6 +4,7 @@
 #include "align_lane_pk16.h"
 #include "align_wave_i32.h"
 #include "align_wave_pk16.h"
+#include "align_wave_coop.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -166,11 +167,23 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
     // columns per lane of the cooperative kernel: 4 (more, shorter steps in flight) while all wavefronts of
     // the batch stay resident, else 8; SA_COOP_C=4|8 pins it
     const long coop_opt = opt.coop_c;
-    const int coop_env = coop_opt == 4 || coop_opt == 8 ? (int)coop_opt : 0;
-    const int coop_c = coop_env ? coop_env : ((uint64_t)b.n * ((max_q + 255) / 256) <= 2048 ? 4 : 8);
-    const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
     const long force_coop = opt.force_coop;
-    pl.coop = allow_coop && b.n * strips8 <= 2048 && (force_coop >= 0 ? force_coop != 0 : (b.n <= 256 && max_q > 1024));
+    const bool coop_wanted = allow_coop && (force_coop >= 0 ? force_coop != 0 : (b.n <= 256 && max_q > 1024));
+    int coop_c = 0;
+    if (b.type == SA_LOCAL) {
+      // columns per lane of the cooperative Local kernel: 4 (more, shorter steps in flight) while all
+      // wavefronts of the batch stay resident, else 8; the option "coop_c" = 4 | 8 pins it
+      coop_c = coop_opt == 4 || coop_opt == 8 ? (int)coop_opt : ((uint64_t)b.n * ((max_q + 255) / 256) <= 2048 ? 4 : 8);
+    } else {
+      // Global / Semiglobal: the narrowest strips (2, 4 or 8 columns per lane) that still give every strip of
+      // the batch a SIMD of its own - a single pair is bound by the length of one step, see align_wave_coop.h
+      for (int c : {2, 4, 8})
+        if (!coop_c && (uint64_t)b.n * ((max_q + 64 * c - 1) / (64 * c)) <= 1024) coop_c = c;
+      if (!coop_c) coop_c = 8;
+      if (coop_opt == 2 || coop_opt == 4 || coop_opt == 8) coop_c = (int)coop_opt;
+    }
+    const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
+    pl.coop = coop_wanted && b.n * strips8 <= 2048;
     // A small batch of short queries is bound by the time of one step, not by throughput: 4 or 8 columns
     // per lane instead of 16 put more lanes of the wavefront to work and shorten the step.
     const bool narrow = !pl.coop && max_q <= 512 && b.n <= 4096;
@@ -186,6 +199,8 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
     pl.pairs_per_unit = pl.wave_pk ? 2 : 1;
     pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 *
                           (pl.wave_pk ? 8 : pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
+    if (pl.coop && b.type != SA_LOCAL)  // one dword per lane per 16 / C steps
+      pl.dirs_unit_stride = (uint64_t)pl.nstrips * (coop_steps_padded(max_t) * pl.wave_c / 16) * 64;
     pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * 2 * (pl.coop ? 2 : 1);  // 64-bit entries
   } else if (pk16_ok) {
     pl.family = Family::LanePk16;
@@ -377,6 +392,31 @@ int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, 
   return SA_OK;
 }
 
+template <int MODE, int C>
+int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback) {
+  if constexpr (MODE == SA_LOCAL) {
+    return fail(SA_ERR_ARGUMENT, "cooperative Global / Semiglobal kernel chosen for Local");
+  } else {
+    {
+      Timed tm(stream, 1);
+      const size_t waves = (size_t)a.pairs_in_pass * a.nstrips;
+      SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
+      // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
+      SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)a.pairs_in_pass * a.brow_unit_stride * 4, stream));
+      hipLaunchKernelGGL((fill_wave_coop2<MODE, C>), dim3((unsigned)waves), dim3(64), 0, stream, a, co);
+    }
+    SA_HIP_TRY(hipGetLastError());
+    if (need_traceback) {
+      {
+        Timed tm(stream, 2);
+        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
+      }
+      SA_HIP_TRY(hipGetLastError());
+    }
+    return SA_OK;
+  }
+}
+
 template <int MODE>
 int launch_wave_pk16(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
   if constexpr (MODE == SA_LOCAL) {
@@ -404,6 +444,10 @@ int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t
                 AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE>(pl, a, stream, need_tb);
+  if (pl.family == Family::WaveI32 && pl.coop && MODE != SA_LOCAL)
+    return pl.wave_c == 2   ? launch_wave_coop2<MODE, 2>(a, co, stream, need_tb)
+           : pl.wave_c == 4 ? launch_wave_coop2<MODE, 4>(a, co, stream, need_tb)
+                            : launch_wave_coop2<MODE, 8>(a, co, stream, need_tb);
   if (pl.family == Family::WaveI32)
     return pl.coop ? (pl.wave_c == 4 ? launch_wave_i32<MODE, 4, true>(a, co, stream, need_tb)
                                      : launch_wave_i32<MODE, 8, true>(a, co, stream, need_tb))
@@ -599,6 +643,15 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
   // threads in all for the one-wavefront-per-pair kernels)
   const size_t max_blocks = std::max<size_t>(1, ((size_t)1 << 22) / pl.pairs_per_block);
   if (blocks_per_pass > max_blocks) blocks_per_pass = max_blocks;
+  if (pl.family == Family::WaveI32 && !pl.coop && blocks_per_pass < total_blocks) {
+    // One wavefront per unit, all of about the same duration: a pass takes as long as the SIMD with the most
+    // wavefronts, so a pass that is cut by the workspace holds a whole number of wavefronts per SIMD
+    // (3200 wavefronts on 1024 SIMDs take four rounds, 3072 take three).
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    const size_t simds = (size_t)cus * 4;
+    if (blocks_per_pass >= simds) blocks_per_pass = blocks_per_pass / simds * simds;
+  }
   const size_t units_per_pass = blocks_per_pass * pl.units_per_block;
   size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 

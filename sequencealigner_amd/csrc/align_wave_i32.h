@@ -364,9 +364,13 @@ template <int C_>
 struct WaveFmtI32 {
   static constexpr int C = C_;
   using word_t = typename WaveWord<C_>::type;
-  static constexpr uint32_t kTileSteps = 64;  // steps of one LDS tile
-  static constexpr uint32_t kPairs = 1;       // pairs that share a wavefront's words
-  __device__ static __forceinline__ uint32_t decode(word_t w, uint32_t k, uint32_t) {
+  static constexpr uint32_t kTileSteps = 64;     // steps of one LDS tile
+  static constexpr uint32_t kStepsPerWord = 1;   // steps whose flags share a word
+  static constexpr uint32_t kTileLanes = (16 / sizeof(word_t)) > 8 ? (16 / sizeof(word_t)) : 8;  // lanes of a tile
+  static constexpr uint32_t kPairs = 1;          // pairs that share a wavefront's words
+  // rows of words per strip (one row = the 64 lanes' words of kStepsPerWord steps)
+  __host__ __device__ static uint32_t rows(uint32_t max_t) { return max_t + 64; }
+  __device__ static __forceinline__ uint32_t decode(word_t w, uint32_t k, uint32_t, uint32_t) {
     return WaveI32Layout<C_>::decode(w, k);
   }
 };
@@ -381,14 +385,17 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   constexpr int C = Fmt::C;
   constexpr uint32_t STRIP = 64 * C;
   constexpr uint32_t TS = Fmt::kTileSteps;
+  constexpr uint32_t SPW = Fmt::kStepsPerWord;          // steps per word; such formats count steps from 0:
+  constexpr uint32_t U0 = SPW > 1 ? 1 : 0;              //   word row of step st = (st - U0) / SPW
+  constexpr uint32_t ROWS = TS / SPW;                   // word rows of one LDS tile
   constexpr uint32_t WPV = 16 / sizeof(word_t);         // words per 16-byte vector
-  constexpr uint32_t TW = WPV > 8 ? WPV : 8;            // lanes (column blocks) of one LDS tile
+  constexpr uint32_t TW = Fmt::kTileLanes;              // lanes (column blocks) of one LDS tile
   constexpr uint32_t VPR = TW / WPV;                    // vectors per tile row
-  constexpr uint32_t kVecPerLane = TS * VPR / 64;       // vectors a lane moves per tile
-  static_assert(TW % WPV == 0 && (TS * VPR) % 64 == 0, "tile shape");
-  __shared__ __attribute__((aligned(16))) word_t tile[TS * TW];
+  constexpr uint32_t kVecPerLane = ROWS * VPR / 64;     // vectors a lane moves per tile
+  static_assert(TW % WPV == 0 && (ROWS * VPR) % 64 == 0 && TS % SPW == 0 && TS % 64 == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) word_t tile[ROWS * TW];
   __shared__ uint8_t qs[STRIP];
-  __shared__ uint8_t ts[128];
+  __shared__ uint8_t ts[TS + 64];
   const uint32_t lane = threadIdx.x;
   const uint32_t pl = blockIdx.x;
   if (pl >= a.pairs_in_pass) return;
@@ -400,15 +407,15 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   const uint32_t T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
   const word_t* dirs =
       reinterpret_cast<const word_t*>(a.dirs + (uint64_t)(pl / Fmt::kPairs) * a.dirs_unit_stride);
-  const uint32_t nsteps = a.max_t + 64;
+  const uint32_t nrows = Fmt::rows(a.max_t);
   uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
   uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
   const bool same = (a.match == a.mismatch);
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
-  // The tile holds steps [tile_lo, tile_lo + TS) x lanes [tile_lb, tile_lb + TW) of strip tile_s: the
-  // path moves towards smaller steps and lanes, about one lane per C diagonal moves.
+  // The tile holds steps [tile_lo, tile_lo + TS) x lanes [tile_lb, tile_lb + TW) of strip tile_s (steps
+  // counted from U0): the path moves towards smaller steps and lanes, about one lane per C diagonal moves.
   uint32_t tile_s = ~0u, tile_lo = 0, tile_lb = 0;
   uint4 pre[kVecPerLane];              // the predicted next tile, on its way in
   uint32_t pre_s = ~0u, pre_lo = 0, pre_lb = 0;
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   };
   auto tile_vec = [&](uint32_t s, uint32_t lo, uint32_t lb, uint32_t x) -> const uint4* {
     const uint32_t v = x * 64 + lane, row = v / VPR, colv = v % VPR;
-    return reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nsteps + lo + row) * 64 + lb) + colv;
+    return reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nrows + lo / SPW + row) * 64 + lb) + colv;
   };
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       if (MODE == SA_LOCAL && remaining == 0) break;  // an inner cell with score 0 is None
       const uint32_t c = r - 1;
       const uint32_t s = c / STRIP, L = (c % STRIP) / C;
-      const uint32_t st = i + L;
+      const uint32_t st = i + L - U0;
       if (s != tile_s || (st & ~(TS - 1)) != tile_lo || L < tile_lb || L >= tile_lb + TW) {
         __syncthreads();
         const uint32_t lo = st & ~(TS - 1);
@@ -457,24 +464,32 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
           tile_s = s;
         }
         tile_lo = lo;
-        // rows of the tile: i = st' - L' for st' in [lo, lo+TS), L' in [0, 63]
-        ts_base = lo >= 64 ? lo - 64 : 0;  // index of row (lo - 63) is lo - 64
+        // rows of the tile: i = st' + U0 - L' for st' in [lo, lo+TS), L' in [0, 63]
+        ts_base = lo + U0 >= 64 ? lo + U0 - 64 : 0;  // index of row (lo + U0 - 63) is lo + U0 - 64
 #pragma unroll
-        for (uint32_t x = 0; x < 2; ++x) {
+        for (uint32_t x = 0; x < (TS + 64) / 64; ++x) {
           const uint32_t idx = ts_base + x * 64 + lane;
           ts[x * 64 + lane] = idx < T ? t[idx] : 0;
         }
-        // the path leaves a tile downwards, TS / C lanes further left on a diagonal: fetch that tile
-        // while walking this one
-        if (lo >= TS) {
+        // Fetch the tile the path is likely to enter next while walking this one.  A diagonal move takes
+        // 1 + 1/C steps: the path leaves through lane 0 into the strip to the left when that comes before
+        // the tile's first step, otherwise downwards, about TS / (C + 1) lanes further left.
+        const uint32_t to_lane0 = (L - tile_lb) * (C + 1);  // steps until a diagonal path passes the tile's first lane
+        if (tile_lb == 0 && s > 0 && to_lane0 + C < st - lo) {
+          pre_s = s - 1;
+          pre_lo = (st - L * (C + 1)) & ~(TS - 1);
+          pre_lb = lane_base(63);
+        } else if (lo >= TS) {
           pre_s = s;
           pre_lo = lo - TS;
-          const uint32_t drift = TS / C > 3 ? TS / C - 3 : 0;
+          const uint32_t drift = TS / (C + 1) > 3 ? TS / (C + 1) - 3 : 0;
           pre_lb = lane_base(L > drift ? L - drift : 0);
-#pragma unroll
-          for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = *tile_vec(s, pre_lo, pre_lb, x);
         } else {
           pre_s = ~0u;
+        }
+        if (pre_s != ~0u) {
+#pragma unroll
+          for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = *tile_vec(pre_s, pre_lo, pre_lb, x);
         }
         __syncthreads();
       }
@@ -483,10 +498,10 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       const uint32_t ix = i - lane, rx = r - lane;
       bool ok = lane < i && lane < r && rx - 1 >= s * STRIP;
       const uint32_t cx = ok ? rx - 1 : c;
-      const uint32_t Lx = (cx % STRIP) / C, kx = cx % C, stx = (ok ? ix : i) + Lx;
+      const uint32_t Lx = (cx % STRIP) / C, kx = cx % C, stx = (ok ? ix : i) + Lx - U0;
       ok = ok && stx >= tile_lo && Lx >= tile_lb;
-      const uint32_t dx =
-          ok ? Fmt::decode(tile[(stx - tile_lo) * TW + (Lx - tile_lb)], kx, half) : (uint32_t)DIR_NONE;
+      const uint32_t dx = ok ? Fmt::decode(tile[((stx - tile_lo) / SPW) * TW + (Lx - tile_lb)], kx, half, stx % SPW)
+                             : (uint32_t)DIR_NONE;
       const bool eqx = ok && ts[ix - 1 - ts_base] == qs[cx % STRIP];
       const uint64_t eqm = __ballot(eqx);
       bool diag_ok = ok && dx == DIR_DIAG;
@@ -534,18 +549,20 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         // read is long) is walked 64 rows per iteration instead of one.  (Local: the score grows on the
         // way up, gap < 0, so no cell of the run is a zero cell.)
         const bool okx = lane < i && st >= tile_lo + lane;
-        const uint32_t ux =
-            okx ? Fmt::decode(tile[(st - lane - tile_lo) * TW + (L - tile_lb)], c % C, half) : (uint32_t)DIR_NONE;
+        const uint32_t ux = okx ? Fmt::decode(tile[((st - lane - tile_lo) / SPW) * TW + (L - tile_lb)], c % C, half,
+                                              (st - lane) % SPW)
+                                : (uint32_t)DIR_NONE;
         const uint64_t um = __ballot(okx && ux == DIR_UP);
         len = ~um ? (uint32_t)__builtin_ctzll(~um) : 64u;  // >= 1: lane 0 is the current cell
       } else if (d == DIR_LEFT) {
         // the same along the row: lane x looks at (i, r - x), as far as the strip and the tile reach
         const bool inx = lane < r && c - lane >= s * STRIP && c >= lane;
         const uint32_t cl = inx ? c - lane : c;
-        const uint32_t Ll = (cl % STRIP) / C, stl = i + Ll;
+        const uint32_t Ll = (cl % STRIP) / C, stl = i + Ll - U0;
         const bool okx = inx && Ll >= tile_lb && stl >= tile_lo;
-        const uint32_t lx =
-            okx ? Fmt::decode(tile[(stl - tile_lo) * TW + (Ll - tile_lb)], cl % C, half) : (uint32_t)DIR_NONE;
+        const uint32_t lx = okx ? Fmt::decode(tile[((stl - tile_lo) / SPW) * TW + (Ll - tile_lb)], cl % C, half,
+                                              stl % SPW)
+                                : (uint32_t)DIR_NONE;
         const uint64_t lm = __ballot(okx && lx == DIR_LEFT);
         len = ~lm ? (uint32_t)__builtin_ctzll(~lm) : 64u;
       }

@@ -32,8 +32,11 @@ struct WaveFmtPk16 {
   static constexpr int C = kWavePkCols;
   using word_t = uint2;
   static constexpr uint32_t kTileSteps = 64;
+  static constexpr uint32_t kStepsPerWord = 1;
+  static constexpr uint32_t kTileLanes = 8;
   static constexpr uint32_t kPairs = 2;
-  __device__ static __forceinline__ uint32_t decode(uint2 w, uint32_t k, uint32_t half) {
+  __host__ __device__ static uint32_t rows(uint32_t max_t) { return max_t + 64; }
+  __device__ static __forceinline__ uint32_t decode(uint2 w, uint32_t k, uint32_t half, uint32_t) {
     const uint32_t word = k < 8 ? w.x : w.y, b = k & 7;
     const uint32_t not_diag = (word >> (16 + 8 * half + b)) & 1u;
     const uint32_t not_left = (word >> (8 * half + b)) & 1u;

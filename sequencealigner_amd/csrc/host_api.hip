@@ -121,13 +121,13 @@ struct Lease {
   }
 };
 
-// Host threads a call may use for staging and text: SA_HOST_THREADS, else OMP_NUM_THREADS, else up to 16.
+// Host threads a call may use for staging and text: SA_HOST_THREADS, else OMP_NUM_THREADS, else every core (at most 64).
 unsigned host_threads() {
   static const unsigned n = [] {
     const char* e = getenv("SA_HOST_THREADS");
     if (!e) e = getenv("OMP_NUM_THREADS");
     unsigned v = e ? (unsigned)atoi(e) : 0;
-    if (!v) v = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (!v) v = std::max(1u, std::thread::hardware_concurrency());
     return std::min(v, 64u);
   }();
   return n;
