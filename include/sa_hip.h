@@ -196,8 +196,11 @@ void sa_free(void* p);
  * sequence s owns triples [d_out_off[s], d_out_off[s+1]) of d_out.  out_capacity is in triples;
  * sa_minimize_out_capacity() gives a sufficient value.  d_status (one int, optional) receives SA_OK,
  * SA_ERR_CAPACITY or SA_ERR_RANGE, written by the device when the work completes.
- * Requires 1 <= k <= 16, w >= 1, every length >= k + w - 1 and, for SA_MIN_BINARY, w <= k + 1 (outside that
- * the reference reads out of bounds; the call is rejected with SA_ERR_ARGUMENT).  SA_MIN_DECIMAL with
+ * Requires 1 <= k <= 31, w >= 1, every length >= k + w - 1 and, for SA_MIN_BINARY, w <= k + 1; other arguments
+ * are rejected with SA_ERR_ARGUMENT.  For k > 16 the values are those of the reference's 32-bit arithmetic
+ * (the last 16 bases of the k-mer, src/minimizer_binary.cpp:53-78).  The limits k <= 31 and w <= k + 1 are this
+ * implementation's (it tracks at most 32 candidate positions per strand); the reference itself runs w > k + 1
+ * and reads past its k-mer list only near the end of a sequence.  SA_MIN_DECIMAL with
  * k > 10 is rejected with SA_ERR_RANGE (every 11-digit value overflows the reference's stoi unless it
  * starts with zeros); for k = 10 the range is checked per k-mer on the device (d_status).
  * d_seq must be readable up to 8 bytes past off[n] (bases are fetched eight at a time).

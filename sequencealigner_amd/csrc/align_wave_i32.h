@@ -482,8 +482,10 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         } else if (lo >= TS) {
           pre_s = s;
           pre_lo = lo - TS;
-          const uint32_t drift = TS / (C + 1) > 3 ? TS / (C + 1) - 3 : 0;
-          pre_lb = lane_base(L > drift ? L - drift : 0);
+          // lanes the path moves left before it leaves this tile downwards; one lane of slack upwards, since
+          // Up moves use steps without changing the lane
+          const uint32_t drift = (st - lo) / (C + 1);
+          pre_lb = lane_base(L + 1 > drift ? (L + 1 - drift < 63 ? L + 1 - drift : 63) : 0);
         } else {
           pre_s = ~0u;
         }
@@ -539,6 +541,28 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
             cur_len = len;
           }
           done += len;
+        }
+        // Lane n looked at the cell the run stopped at: when that is a gap move (and, for Local, not a cell
+        // with score 0, which is None whatever its flags say), take it in the same iteration - single gaps
+        // between diagonal stretches are the common case, and this halves the number of iterations.
+        const uint32_t dn = n < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)dx, (int)n) : (uint32_t)DIR_NONE;
+        if ((dn == DIR_UP || dn == DIR_LEFT) && (MODE != SA_LOCAL || remaining != 0)) {
+          const uint32_t op = dn == DIR_LEFT ? SA_OP_I : SA_OP_D;
+          if (dn == DIR_LEFT)
+            r -= 1;
+          else
+            i -= 1;
+          if (MODE == SA_LOCAL) remaining -= a.gap;
+          if (op == cur_op) {
+            cur_len += 1;
+          } else {
+            if (cur_len) {
+              ++nruns;
+              if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
+            }
+            cur_op = op;
+            cur_len = 1;
+          }
         }
         continue;
       }

@@ -345,17 +345,23 @@ __global__ __launch_bounds__(kThreads) void dec_run(MinArgs a) {
 // ---- sort / unique / output ---------------------------------------------------------------------
 // Sequence s's keys are [wbase[s], wbase[s] + counter[s]) of the key array; the unique pass walks them
 // in tiles of kTile keys.
+// big_end / n_big: sequences with more than kTile keys are "big" - they are left to the segmented radix sort,
+// whose segment s is [seg_begin[s], big_end[s]) (empty for the others, which are sorted inside LDS).
 __global__ void min_segments(const uint32_t* wbase, const uint32_t* counter, uint32_t n,
-                             uint32_t* seg_begin, uint32_t* seg_end, uint32_t* tiles) {
+                             uint32_t* seg_begin, uint32_t* seg_end, uint32_t* big_end, uint32_t* tiles,
+                             uint32_t* n_big) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > n) return;
   if (s == n) {
     tiles[s] = 0;
     return;
   }
+  const uint32_t c = counter[s];
   seg_begin[s] = wbase[s];
-  seg_end[s] = wbase[s] + counter[s];
-  tiles[s] = (counter[s] + kTile - 1) / kTile;
+  seg_end[s] = wbase[s] + c;
+  big_end[s] = c > kTile ? wbase[s] + c : wbase[s];
+  if (c > kTile) atomicAdd(n_big, 1u);
+  tiles[s] = (c + kTile - 1) / kTile;
 }
 
 struct UniqArgs {
@@ -455,22 +461,16 @@ __device__ __forceinline__ uint32_t value_bin(uint32_t v, uint32_t value_bits) {
 
 __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uint64_t* sorted,
                                                        const uint32_t* seg_begin, const uint32_t* seg_end,
-                                                       uint32_t* big_end, const uint32_t* tile_base,
-                                                       uint32_t* tile_count, uint32_t key_shift,
-                                                       uint32_t value_bits, uint32_t* n_big) {
+                                                       const uint32_t* tile_base, uint32_t* tile_count,
+                                                       uint32_t key_shift, uint32_t value_bits,
+                                                       const uint32_t* n_big) {
   __shared__ uint64_t grouped[kSmallMax];
   __shared__ uint32_t bins[kBins];
   __shared__ uint32_t lds[kThreads / 64];
+  if (*n_big == 0) return;  // a batch without big sequences is served by sort_emit_small
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   const uint32_t begin = seg_begin[s], count = seg_end[s] - begin;
-  if (count > kSmallMax || count == 0) {
-    if (tid == 0) {
-      big_end[s] = seg_end[s];
-      if (count) atomicAdd(n_big, 1u);
-    }
-    return;
-  }
-  if (tid == 0) big_end[s] = begin;
+  if (count > kSmallMax || count == 0) return;
   constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
 #pragma unroll
   for (uint32_t e = 0; e < kBinsPer; ++e) bins[tid + e * kThreads] = 0;
@@ -530,6 +530,182 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
   if (tid == 0) tile_count[tile_base[s]] = total;
 }
 
+
+// ---- sort + unique + output in one kernel, for batches in which every sequence has at most kSmallMax keys
+// (reads).  One block per sequence: the counting sort of sort_small, then the block knows its number of
+// distinct keys and needs the number of all sequences before it: a single-pass chained scan with look-back
+// (every block publishes its own count at once and its inclusive prefix as soon as it knows it; a block adds
+// up the counts of its predecessors backwards until it meets one that already has its prefix).  Sequence
+// numbers are handed out by a ticket counter in start order, so a block only ever waits for blocks that
+// already run.  The triples are staged in LDS and leave as one contiguous run: the sorted keys never travel
+// to memory and back.
+constexpr uint64_t kScanCount = 1ull << 62, kScanPrefix = 2ull << 62, kScanValue = (1ull << 62) - 1;
+
+struct EmitArgs {
+  const uint64_t* keys;
+  const uint32_t* seg_begin;
+  const uint32_t* seg_end;
+  uint32_t n;
+  uint32_t key_shift, value_bits;
+  uint64_t* scan_state;  // n entries, zeroed: flag << 62 | value
+  uint32_t* ticket;      // zeroed
+  const uint32_t* n_big; // sequences with more than kSmallMax keys
+  uint64_t out_capacity;
+  uint32_t* out;
+  uint64_t* out_off;
+  int* status;
+};
+
+__global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
+  // one buffer, three uses: [0, 4096) grouped keys, [4096, 6144) bins, [6144, 10240) sorted keys; the triples are
+  // staged over the first two once the sort is done
+  __shared__ __attribute__((aligned(16))) uint32_t buf[5 * kSmallMax];
+  __shared__ uint32_t lds[kThreads / 64];
+  __shared__ uint32_t s_seq;
+  __shared__ uint64_t s_excl;
+  uint64_t* grouped = reinterpret_cast<uint64_t*>(buf);
+  uint32_t* bins = buf + 2 * kSmallMax;
+  uint64_t* sorted = reinterpret_cast<uint64_t*>(buf + 3 * kSmallMax);
+  uint32_t* stage = buf;
+  static_assert(kBins == kSmallMax, "LDS layout");
+  const uint32_t tid = threadIdx.x;
+  if (*a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
+  if (tid == 0) s_seq = atomicAdd(a.ticket, 1u);
+  __syncthreads();
+  const uint32_t s = s_seq;
+  if (s >= a.n) return;
+  const uint32_t begin = a.seg_begin[s], count = a.seg_end[s] - begin;  // count <= kSmallMax (checked by the host)
+  constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
+#pragma unroll
+  for (uint32_t e = 0; e < kBinsPer; ++e) bins[tid + e * kThreads] = 0;
+  __syncthreads();
+  uint64_t mine[kPer];
+  uint32_t bin[kPer];
+#pragma unroll
+  for (uint32_t e = 0; e < kPer; ++e) {
+    const uint32_t i = tid + e * kThreads;
+    if (i < count) {
+      mine[e] = a.keys[begin + i];
+      bin[e] = value_bin((uint32_t)(mine[e] >> a.key_shift), a.value_bits);
+      atomicAdd(&bins[bin[e]], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t local[kBinsPer], sum = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < kBinsPer; ++e) {
+    local[e] = bins[tid * kBinsPer + e];
+    sum += local[e];
+  }
+  uint32_t excl;
+  block_sum(sum, lds, &excl);
+#pragma unroll
+  for (uint32_t e = 0; e < kBinsPer; ++e) {
+    bins[tid * kBinsPer + e] = excl;
+    excl += local[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t e = 0; e < kPer; ++e) {
+    const uint32_t i = tid + e * kThreads;
+    if (i < count) grouped[atomicAdd(&bins[bin[e]], 1u)] = mine[e];
+  }
+  __syncthreads();
+  // bins[b] is now the end of bin b: rank every key among the keys of its bin
+  for (uint32_t p = tid; p < count; p += kThreads) {
+    const uint64_t key = grouped[p];
+    const uint32_t b = value_bin((uint32_t)(key >> a.key_shift), a.value_bits);
+    const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
+    uint32_t rank = 0;
+    for (uint32_t m = lo; m < hi; ++m) {
+      const uint64_t other = grouped[m];
+      rank += (other < key || (other == key && m < p)) ? 1u : 0u;
+    }
+    sorted[lo + rank] = key;
+  }
+  __syncthreads();
+  // distinct keys: thread t looks at the kPer consecutive sorted keys t*kPer ..
+  uint64_t k8[kPer];
+  uint32_t flags = 0;
+  {
+    const uint32_t first = tid * kPer;
+    uint64_t prev = (first > 0 && first < count) ? sorted[first - 1] : 0;
+#pragma unroll
+    for (uint32_t e = 0; e < kPer; ++e) {
+      const uint32_t i = first + e;
+      if (i < count) {
+        k8[e] = sorted[i];
+        if (i == 0 || k8[e] != prev) flags |= 1u << e;
+        prev = k8[e];
+      }
+    }
+  }
+  uint32_t uexcl;
+  const uint32_t uniq = block_sum(__builtin_popcount(flags), lds, &uexcl);  // (ends with a barrier)
+  // this sequence's place among all sequences: look back over the predecessors' counts
+  if (tid < 64) {
+    const uint32_t lane = tid;
+    if (lane == 0)
+      __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t before = 0;
+    int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
+    uint32_t polls = 0;
+    while (top >= 0) {
+      const int64_t idx = top - lane;
+      uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
+      if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t ready = __ballot((st >> 62) != 0);
+      const uint64_t final = __ballot((st >> 62) == 2);
+      // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the window
+      // has no prefix and all 64 are ready)
+      const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
+      const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
+      if ((ready & need) != need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
+          if (lane == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
+          break;
+        }
+        continue;
+      }
+      uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      before += v;
+      if (final) break;
+      top -= 64;
+    }
+    if (lane == 0) {
+      if (s != 0)
+        __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = before;
+      a.out_off[s] = before;
+      if (s + 1 == a.n) {
+        a.out_off[a.n] = before + uniq;
+        if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
+      }
+    }
+  }
+  // stage the triples (the grouped keys and the bins are no longer needed) and write them as one run
+  uint32_t r = uexcl;
+  const uint64_t low = (1ull << a.key_shift) - 1;
+#pragma unroll
+  for (uint32_t e = 0; e < kPer; ++e) {
+    if (!((flags >> e) & 1u)) continue;
+    stage[3 * r] = (uint32_t)(k8[e] >> a.key_shift);
+    stage[3 * r + 1] = (uint32_t)((k8[e] & low) >> 1);
+    stage[3 * r + 2] = (uint32_t)(k8[e] & 1);
+    ++r;
+  }
+  __syncthreads();
+  const uint64_t first_out = s_excl;
+  const uint64_t room = first_out < a.out_capacity ? a.out_capacity - first_out : 0;
+  const uint32_t dwords = 3 * (uint32_t)(uniq < room ? uniq : room);
+  uint32_t* dst = a.out + 3 * first_out;
+  for (uint32_t x = tid; x < dwords; x += kThreads) dst[x] = stage[x];
+}
+
 __global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
   __shared__ uint32_t lds[kThreads / 64];
   if (u.skip_small && *u.n_big == 0) return;  // every tile was counted by sort_small
@@ -549,6 +725,7 @@ __global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
 __global__ __launch_bounds__(kThreads) void uniq_write(UniqArgs u) {
   __shared__ uint32_t lds[kThreads / 64];
   __shared__ uint32_t stage[3 * kTile];
+  if (u.skip_small && *u.n_big == 0) return;  // sort_emit_small has written the output
   const uint32_t tiles = u.tile_base[u.n];
   const uint64_t low = (1ull << u.key_shift) - 1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -594,7 +771,7 @@ struct MinPlan {
   size_t total_bytes;
   // workspace offsets
   size_t o_nchunks, o_chunk_base, o_windows, o_wbase, o_counter, o_exit_f, o_exit_c, o_resolved, o_keys,
-      o_sorted, o_seg_begin, o_seg_end, o_big_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_tmp;
+      o_sorted, o_seg_begin, o_seg_end, o_big_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_scan_state, o_tmp;
 };
 
 uint32_t bits_for(uint64_t v) {
@@ -608,7 +785,7 @@ uint32_t bits_for(uint64_t v) {
 
 int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, uint32_t w, int variant,
                   MinPlan* pl) {
-  if (k < 1 || k > 16 || w < 1) return SA_ERR_ARGUMENT;
+  if (k < 1 || k > 31 || w < 1) return SA_ERR_ARGUMENT;
   if (variant == SA_MIN_BINARY && w > k + 1) return SA_ERR_ARGUMENT;
   if (variant == SA_MIN_DECIMAL && k > 10) return SA_ERR_RANGE;
   const uint64_t span = (uint64_t)k + w - 2;
@@ -624,7 +801,8 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->max_tiles = (uint32_t)(pl->capacity / kTile + n);
   // w = 1 can emit k-mer 0, whose value the reference builds without the mask: with a non-base byte in it
   // the value has ones above its 2k bits
-  const uint32_t value_bits = (variant == SA_MIN_BINARY) ? (w == 1 ? 32 : 2 * k) : 31;
+  // (k > 16: the reference's 32-bit values keep the last 16 bases of a k-mer)
+  const uint32_t value_bits = (variant == SA_MIN_BINARY) ? ((w == 1 || k > 16) ? 32 : 2 * k) : 31;
   pl->key_shift = bits_for(max_len) + 1;
   pl->end_bit = pl->key_shift + value_bits;
   if (pl->end_bit > 64) return SA_ERR_ARGUMENT;
@@ -664,6 +842,7 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_tile_base = take(n1);
   pl->o_tile_count = take(mt * 4);
   pl->o_tile_off = take(mt * 8);
+  pl->o_scan_state = take(((size_t)n + 1) * 8);  // look-back scan of the fused sort/output kernel + its ticket
   pl->o_tmp = take(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), pl->sort_tmp));
   pl->total_bytes = o;
   return SA_OK;
@@ -696,8 +875,8 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     return fail(SA_ERR_ARGUMENT, "unknown minimizer variant %d", b->variant);
   if (!b->d_seq || !b->d_off || !b->d_out || !b->d_out_off)
     return fail(SA_ERR_ARGUMENT, "NULL sequence/offset/output pointer");
-  if (b->k < 1 || b->k > 16 || b->w < 1 || (b->variant == SA_MIN_BINARY && b->w > b->k + 1))
-    return fail(SA_ERR_ARGUMENT, "need 1 <= k <= 16, w >= 1 and (MinimizeBinary) w <= k + 1 (k=%u, w=%u)",
+  if (b->k < 1 || b->k > 31 || b->w < 1 || (b->variant == SA_MIN_BINARY && b->w > b->k + 1))
+    return fail(SA_ERR_ARGUMENT, "need 1 <= k <= 31, w >= 1 and (MinimizeBinary) w <= k + 1 (k=%u, w=%u)",
                 b->k, b->w);
   if (b->min_len < b->k + b->w - 1)
     return fail(SA_ERR_ARGUMENT, "every sequence must have at least k + w - 1 = %u bases (min_len=%u)",
@@ -764,22 +943,27 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, windows, wbase, 0u, (size_t)b->n + 1,
                                      rocprim::plus<uint32_t>(), stream));
   if (b->variant == SA_MIN_BINARY) {
-    auto* run = b->w == 5 ? min_run<Machine<5>> : b->w == 10 ? min_run<Machine<10>> : min_run<Machine<0>>;
+    const bool long_k = b->k > 16;  // a third history word
+    auto* run = long_k     ? min_run<Machine<0, true>>
+                : b->w == 5  ? min_run<Machine<5>>
+                : b->w == 10 ? min_run<Machine<10>>
+                             : min_run<Machine<0>>;
     hipLaunchKernelGGL(run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
-    hipLaunchKernelGGL(min_fix<Machine<0>>, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a,
-                       n_unresolved);
+    auto* fix = long_k ? min_fix<Machine<0, true>> : min_fix<Machine<0>>;
+    hipLaunchKernelGGL(fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
     // a batch with bytes other than bases runs again on the exact machine (the three kernels return at
     // once otherwise)
     hipLaunchKernelGGL(min_redo_reset, blocks((uint64_t)b->n + 1), dim3(kThreads), 0, stream, counter, b->n,
                        other);
-    hipLaunchKernelGGL(min_run<MachineX>, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
-    hipLaunchKernelGGL(min_fix<MachineX>, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a,
-                       n_unresolved);
+    auto* run_x = long_k ? min_run<MachineX<true>> : min_run<MachineX<false>>;
+    auto* fix_x = long_k ? min_fix<MachineX<true>> : min_fix<MachineX<false>>;
+    hipLaunchKernelGGL(run_x, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
+    hipLaunchKernelGGL(fix_x, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
   } else {
     hipLaunchKernelGGL(dec_run, blocks(b->n), dim3(kThreads), 0, stream, a);
   }
   hipLaunchKernelGGL(min_segments, blocks(b->n + 1), dim3(kThreads), 0, stream, wbase, counter, b->n,
-                     seg_begin, seg_end, tiles);
+                     seg_begin, seg_end, big_end, tiles, n_big);
   SA_HIP_TRY(hipGetLastError());
   t = pl.scan32_tmp;
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tiles, tile_base, 0u, (size_t)b->n + 1,
@@ -794,8 +978,26 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     if (count)
       SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
   } else {
+    // no sequence with more than kSmallMax keys (reads): one kernel sorts, removes duplicates and writes
+    // the triples; otherwise it returns at once and the kernels after it do the work
+    EmitArgs ea{};
+    ea.keys = keys;
+    ea.seg_begin = seg_begin;
+    ea.seg_end = seg_end;
+    ea.n = b->n;
+    ea.key_shift = pl.key_shift;
+    ea.value_bits = pl.end_bit - pl.key_shift;
+    ea.scan_state = (uint64_t*)(ws + pl.o_scan_state);
+    ea.ticket = (uint32_t*)(ea.scan_state + b->n);
+    ea.n_big = n_big;
+    ea.out_capacity = b->out_capacity;
+    ea.out = b->d_out;
+    ea.out_off = b->d_out_off;
+    ea.status = b->d_status;
+    SA_HIP_TRY(hipMemsetAsync(ea.scan_state, 0, ((size_t)b->n + 1) * 8, stream));
+    hipLaunchKernelGGL(sort_emit_small, dim3(b->n), dim3(kThreads), 0, stream, ea);
     hipLaunchKernelGGL(sort_small, dim3(b->n), dim3(kThreads), 0, stream, keys, sorted, seg_begin, seg_end,
-                       big_end, tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift, n_big);
+                       tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift, n_big);
     SA_HIP_TRY(hipGetLastError());
     if (!all_small)
       SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,

@@ -24,7 +24,11 @@
 // order from the exit state of their predecessor.
 //
 // All k-mer values a step can need lie in the last 2k bases, so the history is one 64-bit register pair
-// and every value is a shift and a mask.  The other strand is never materialised: its order is the
+// and every value is a shift and a mask.  For k > 16 the reference's 32-bit values wrap (:53-78: the left
+// shifts drop the high bits, getMask saturates at 0xFFFFFFFF): a k-mer's value is its LAST 16 bases, while
+// positions, the expiry rule and the window count still use k.  The machines then keep a third history word
+// (LONG): the k-mer that starts `back` positions before the newest one ends `back` bases before the newest
+// base, back <= k <= 31, and its 32 value bits need 2 * back + 32 <= 94 bits of history.  The other strand is never materialised: its order is the
 // reverse of the forward order, so its minimum is the forward maximum.  That identity needs every byte to
 // be a base: Machine only notices other bytes (other4 / other1), and a batch that has any is run again
 // with MachineX, which carries a second history of "not a base" marks and both strands' values.
@@ -86,7 +90,7 @@ __device__ __forceinline__ uint64_t make_key(uint32_t value, uint32_t pos, uint3
 
 // The two-strand state machine of one thread.  W > 0 fixes the window length at compile time (the scan
 // over the window unrolls); W = 0 takes it from reset().
-template <uint32_t W>
+template <uint32_t W, bool LONG = false>
 struct Machine {
   // how the kernels feed bases: feed1 / feed4 turn 1 / 4 bytes into the per-base argument(s) of push() and
   // step() (8 bits apart in feed4), kFeedMask extracts one; `other` collects evidence of non-base bytes
@@ -101,7 +105,7 @@ struct Machine {
     return base_code4(bytes);
   }
 
-  uint32_t lo, hi;          // the last 32 base codes, newest in the low bits of lo
+  uint32_t lo, hi, hi2;     // the last 32 (LONG: 48) base codes, newest in the low bits of lo
   uint32_t pf, vf, pc, vc;  // per strand: position of the minimum and its FORWARD value
   uint32_t j;               // k-mer the next step brings in (the step consumes base j + k - 1)
   uint32_t k, w, mask;
@@ -113,15 +117,21 @@ struct Machine {
     k = k_;
     w = W ? W : w_;
     mask = (k_ >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k_)) - 1u);
-    lo = hi = 0;
+    lo = hi = hi2 = 0;
     pf = pc = vf = vc = j = 0;
   }
   __device__ __forceinline__ void push(uint32_t code) {
+    if (LONG) hi2 = __builtin_amdgcn_alignbit(hi2, hi, 30);
     hi = __builtin_amdgcn_alignbit(hi, lo, 30);
     lo = (lo << 2) | code;
   }
   // forward value of the k-mer that starts `back` positions before the newest complete k-mer
   __device__ __forceinline__ uint32_t value_back(uint32_t back) const {
+    if (LONG) {  // bits [2 * back, 2 * back + 32) of hi2:hi:lo
+      const uint32_t sh = 2 * back;
+      const uint32_t w0 = sh < 32 ? lo : hi, w1 = sh < 32 ? hi : hi2;
+      return __builtin_amdgcn_alignbit(w1, w0, sh & 31u);
+    }
     const uint64_t h = ((uint64_t)hi << 32) | lo;
     return (uint32_t)(h >> (2 * back)) & mask;
   }
@@ -250,6 +260,7 @@ struct Machine {
 // The state machine for sequences with bytes other than bases: same interface as Machine, both strands'
 // values explicit.  A second history holds a mark (binary 11) for every such byte; a k-mer's value is its
 // codes OR-ed with ones from its newest mark upwards - within the 2k-bit mask, except for k-mer 0.
+template <bool LONG = false>
 struct MachineX {
   static constexpr bool kExact = true;
   static constexpr uint32_t kFeedMask = 7u;  // code | mark << 2
@@ -265,27 +276,36 @@ struct MachineX {
     return base_code4(bytes) | (nz >> 5);
   }
 
-  uint32_t lo, hi, mlo, mhi;  // codes and marks of the last 32 bytes, newest in the low bits
-  uint32_t pf, vf, pc, vc;    // per strand: position of the minimum and the strand's own value
+  uint32_t lo, hi, hi2, mlo, mhi, mhi2;  // codes and marks of the last 32 (LONG: 48) bytes, newest in the low bits
+  uint32_t pf, vf, pc, vc;               // per strand: position of the minimum and the strand's own value
   uint32_t j, k, w, mask;
 
   __device__ __forceinline__ void reset(uint32_t k_, uint32_t w_) {
     k = k_;
     w = w_;
     mask = (k_ >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k_)) - 1u);
-    lo = hi = mlo = mhi = 0;
+    lo = hi = hi2 = mlo = mhi = mhi2 = 0;
     pf = pc = vf = vc = j = 0;
   }
   __device__ __forceinline__ void push(uint32_t fed) {
+    if (LONG) hi2 = __builtin_amdgcn_alignbit(hi2, hi, 30);
     hi = __builtin_amdgcn_alignbit(hi, lo, 30);
     lo = (lo << 2) | (fed & 3u);
+    if (LONG) mhi2 = __builtin_amdgcn_alignbit(mhi2, mhi, 30);
     mhi = __builtin_amdgcn_alignbit(mhi, mlo, 30);
     mlo = (mlo << 2) | ((fed & 4u) ? 3u : 0u);
   }
+  __device__ static __forceinline__ uint32_t window32(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t back) {
+    if (LONG) {  // bits [2 * back, 2 * back + 32) of w2:w1:w0
+      const uint32_t sh = 2 * back;
+      return __builtin_amdgcn_alignbit(sh < 32 ? w1 : w2, sh < 32 ? w0 : w1, sh & 31u);
+    }
+    return (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * back));
+  }
   // Both strands' values of k-mer `index`, which starts `back` positions before the newest complete one.
   __device__ __forceinline__ void values(uint32_t back, uint32_t index, uint32_t* f, uint32_t* c) const {
-    const uint32_t raw = (uint32_t)((((uint64_t)hi << 32) | lo) >> (2 * back)) & mask;
-    const uint32_t marks = (uint32_t)((((uint64_t)mhi << 32) | mlo) >> (2 * back)) & mask;
+    const uint32_t raw = window32(lo, hi, hi2, back) & mask;
+    const uint32_t marks = window32(mlo, mhi, mhi2, back) & mask;
     uint32_t ones = marks ? 0u - (marks & (0u - marks)) : 0u;  // from the newest mark upwards
     if (index != 0) ones &= mask;
     *f = raw | ones;

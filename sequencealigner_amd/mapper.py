@@ -4,19 +4,41 @@ spans, CIGAR statistics - then one PAF record per read (generatePAFString, :354-
 
 Branches of mapping() (:421-442): a read with a chain, a chained reference span below 100 000 and a length
 below 5 000 is aligned when CIGARs are wanted; otherwise a record without CIGAR reports chain length * k and
-the larger of the two spans; a read without a chain gets the "-1" record when CIGARs are wanted."""
+the larger of the two spans; a read without a chain gets the "-1" record when CIGARs are wanted.
+
+Keyword defaults here are gap = -1 and cigar_needed = True (what the alignment benchmarks use); the mapper's
+command line defaults to gap 0 and no CIGAR (src/mapper.cpp:467-468) - sequencealigner_amd/cli.py passes the
+mapper's values.  A read shorter than k + w - 1 bases has no window: the reference's loop bound underflows
+there (src/minimizer_binary.cpp:161, outside its defined behaviour); here such a read simply has no minimizers
+and therefore no chain, and the other reads of the file are unaffected."""
 import numpy as np
 import torch
 
 from . import align, chain, ingest, minimize, paf
 
 
+def _spread_offsets(sub_off, keep, n, device):
+    """Offsets [n + 1] of all n sequences from the offsets of the kept ones (the others own empty lists)."""
+    counts = np.zeros(n, dtype=np.int64)
+    counts[keep] = np.diff(sub_off.cpu().numpy())
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    return torch.from_numpy(off).to(torch.device("cuda", device))
+
+
 def _device_lists(seqs, k, w, device):
-    b = minimize.DeviceMinimizeBatch(seqs, k, w, device=device)
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    keep = np.nonzero(lens >= k + w - 1)[0]
+    if keep.size == 0:
+        dev = torch.device("cuda", device)
+        return torch.zeros((0, 3), dtype=torch.int32, device=dev), torch.zeros(len(seqs) + 1, dtype=torch.int64, device=dev)
+    b = minimize.DeviceMinimizeBatch([seqs[i] for i in keep] if keep.size < len(seqs) else seqs, k, w, device=device)
     b.run()
     torch.cuda.synchronize(device)
     off = b.d_out_off.clone()
     n = int(off[-1].item())
+    if keep.size < len(seqs):
+        off = _spread_offsets(off, keep, len(seqs), device)
     return b.d_out[:3 * n].clone().reshape(n, 3), off
 
 
@@ -78,12 +100,26 @@ def map_reads(ref_name, ref_seq, read_names, reads, k=15, w=5, f=0.001, match=1,
 
 
 def _records_lists(rec, k, w, device):
-    b = minimize.DeviceMinimizeBatch.from_device(rec.d_seq, rec.d_seq_off, rec.n, rec.n_bases, rec.min_len,
-                                                 rec.max_len, k, w, device=device)
+    keep = None
+    if rec.min_len < k + w - 1:  # some records have no window: minimizers of the others only
+        lens = rec.lengths()
+        keep = np.nonzero(lens >= k + w - 1)[0]
+        dev = torch.device("cuda", device)
+        if keep.size == 0:
+            return torch.zeros((0, 3), dtype=torch.int32, device=dev), torch.zeros(rec.n + 1, dtype=torch.int64, device=dev)
+        starts = rec.d_seq_off.cpu().numpy()[:-1]
+        d_seq, d_off = ingest.gather_spans(rec.d_seq, starts[keep], lens[keep], device)
+        b = minimize.DeviceMinimizeBatch.from_device(d_seq, d_off, keep.size, int(lens[keep].sum()), int(lens[keep].min()),
+                                                     int(lens[keep].max()), k, w, device=device)
+    else:
+        b = minimize.DeviceMinimizeBatch.from_device(rec.d_seq, rec.d_seq_off, rec.n, rec.n_bases, rec.min_len,
+                                                     rec.max_len, k, w, device=device)
     b.run()
     torch.cuda.synchronize(device)
     off = b.d_out_off.clone()
     n = int(off[-1].item())
+    if keep is not None:
+        off = _spread_offsets(off, keep, rec.n, device)
     return b.d_out[:3 * n].clone().reshape(n, 3), off
 
 
@@ -128,9 +164,11 @@ def map_records(ref, ref_name, reads, read_names, k=15, w=5, f=0.001, match=1, m
     return out
 
 
-def map_files(ref_path, reads_path, **kw):
+def map_files(ref_path, reads_path, details=None, **kw):
     """The mapper's main path from two file names (reference src/mapper.cpp:532-679): reference FASTA, reads
-    FASTA or FASTQ by the mapper's file-name tests; returns the PAF records."""
+    FASTA or FASTQ by the mapper's file-name tests; returns the PAF records.  `details` (a dict, optional)
+    receives what the mapper prints besides the records: "ref" / "reads" (the DeviceRecords), their names and
+    the host copies of the files."""
     device = kw.get("device", 0)
     ref_bytes = np.fromfile(ref_path, dtype=np.uint8)
     read_bytes = np.fromfile(reads_path, dtype=np.uint8)
@@ -142,4 +180,6 @@ def map_files(ref_path, reads_path, **kw):
     reads = ingest.DeviceRecords(torch.from_numpy(read_bytes).to(dev), fmt, device)
     ref_name = ref.names(ref_bytes.tobytes())[0].decode()
     read_names = [x.decode() for x in reads.names(read_bytes.tobytes())]
+    if details is not None:
+        details.update(ref=ref, reads=reads, ref_name=ref_name, read_names=read_names, read_bytes=read_bytes)
     return map_records(ref, ref_name, reads, read_names, **kw)

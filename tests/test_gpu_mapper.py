@@ -85,3 +85,68 @@ def test_files_to_paf_records_on_the_device(tmp_path):
     order = [i for i in range(len(reads)) if len(reads[i]) >= 5000] + [i for i in range(len(reads)) if len(reads[i]) < 5000]
     want = mapper.map_reads("chrT", ref, names, reads, 15, 5, 0.001, 1, -1, -1, True)
     assert got == [want[i] for i in order]
+
+
+def _write_files(tmp_path, ref, names, reads):
+    fa = tmp_path / "ref.fasta"
+    with open(fa, "wb") as fh:
+        fh.write(b">chrT synthetic\n")
+        for j in range(0, len(ref), 70):
+            fh.write(ref[j:j + 70] + b"\n")
+    fq = tmp_path / "reads.fq"
+    with open(fq, "wb") as fh:
+        for n, r in zip(names, reads):
+            fh.write(b"@" + n.encode() + b" x\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    return str(fa), str(fq)
+
+
+def test_command_line_like_the_mappers(tmp_path, oracle):
+    """sequencealigner_amd.cli with the mapper's flags on generated files: stdout holds exactly the PAF records
+    of map_files for the same settings (the mapper's own defaults when no flag is given), stderr the fragment
+    statistics, the demo alignment (checked against the CPU checker) and the reference index figures.  One
+    read is shorter than k + w - 1: it gets the no-chain record and does not disturb the others."""
+    import io
+    from sequencealigner_amd import cli, mapper, synth
+    rng = random.Random(11)
+    ref = bytes(synth.genome(60_000, seed=91))
+    reads, names = [], []
+    for i in range(60):
+        L = rng.choice([150, 700, 3000, 5200])
+        p = rng.randint(0, len(ref) - L)
+        s = bytearray(ref[p:p + L])
+        for x in range(len(s)):
+            if rng.random() < 0.03:
+                s[x] = rng.choice(b"ACGT")
+        reads.append(bytes(s))
+        names.append("read%d" % i)
+    reads.insert(7, b"ACGTACGTAC")          # 10 bases: no window at k = 15, w = 5
+    names.insert(7, "tiny")
+    fa, fq = _write_files(tmp_path, ref, names, reads)
+    for argv, kw in ((["-c", "1", "-g", "-1", "-a", "2", "--seed", "4"], dict(gap=-1, cigar_needed=True)),
+                     ([], dict(gap=0, cigar_needed=False)),
+                     (["-k", "19", "-w", "10", "--gap=-2", "--cigar", "-t", "8"], dict(k=19, w=10, gap=-2, cigar_needed=True))):
+        out, err = io.StringIO(), io.StringIO()
+        assert cli.main(argv + [fa, fq], out, err) == 0
+        settings = dict(k=15, w=5, f=0.001, match=1, mismatch=-1)
+        settings.update(kw)
+        want = mapper.map_files(fa, fq, **settings)
+        assert out.getvalue() == "".join(want)
+        assert len(want) == len(reads)
+        tiny = [line for line in want if line.startswith("tiny\t")]
+        assert len(tiny) == 1 and tiny[0].split("\t")[2:4] == (["-1", "-1"] if settings["cigar_needed"] else ["0", "0"])
+        text = err.getvalue()
+        assert "Number of sequences: 61\n" in text and "Total length of all fragments: %d\n" % sum(map(len, reads)) in text
+        assert "---------------Alignment---------------" in text and "In reference genome: " in text
+        vals = oracle.minimize_binary_array(ref, settings["k"], settings["w"])[:, 0]
+        size, single, most = cli.index_figures(vals, 0.001)
+        assert "num minimizer:%d\nnum singleton: %d\n" % (size, single) in text
+        if argv[:1] == ["-c"]:   # the demo pair is reproducible with --seed: compare with the CPU checker
+            short = [i for i in range(len(reads)) if len(reads[i]) < 5000]
+            i1, i2 = random.Random(4).sample(short, 2)
+            score, _, tb = oracle.align(reads[i1], reads[i2], 2, 1, -1, -1)
+            if score > 0:
+                assert "Query: %s\n" % names[i1] in text and "Target: %s\n" % names[i2] in text
+                assert "alignment score: %d\ntaget begin: %d\n" % (score, tb) in text
+    out, err = io.StringIO(), io.StringIO()
+    cli.main(["-v", "-h"], out, err)
+    assert err.getvalue() == "v1.0\n" and "kmer len" in out.getvalue()

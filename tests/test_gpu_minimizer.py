@@ -167,3 +167,26 @@ def test_long_sequence_with_gaps_of_n_vs_oracle(oracle):
     for k, w in ((15, 5), (16, 17), (8, 1)):
         got = minimize.minimize_binary(g, k, w)
         assert np.array_equal(got, oracle.minimize_binary_array(g, k, w)), (k, w)
+
+
+def test_k_above_16_vs_oracle(oracle):
+    """k = 17 .. 31 (mapper settings such as -k 19 or -k 21): the reference's 32-bit k-mer values wrap, a value
+    is the last 16 bases of the k-mer (src/minimizer_binary.cpp:53-78) while positions, expiry and the window
+    count use k.  Random reads, constant and periodic stretches, bytes other than bases, one long sequence."""
+    from sequencealigner_amd import minimize, synth
+    rng = random.Random(23)
+    seqs = [bytes(synth.genome(rng.randint(64, 9_000), seed=400 + i)) for i in range(60)]
+    seqs += [b"A" * 3000, b"ACGTTGCA" * 700, bytes(synth.genome(2000, seed=7)) + b"N" * 40 + bytes(synth.genome(3000, seed=8)),
+             bytes(synth.genome(120_000, seed=9)), b"acgtn" * 500]
+    for k, w in ((17, 5), (19, 10), (21, 11), (24, 25), (31, 32), (31, 1), (20, 5)):
+        batch = [s for s in seqs if len(s) >= k + w - 1]
+        res = minimize.minimize_batch(batch, k, w)
+        for s, r in zip(batch, res):
+            assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s))
+    # the single-sequence call (device-wide sort) as well
+    g = bytes(synth.genome(300_000, seed=10))
+    assert np.array_equal(minimize.minimize_binary(g, 21, 11), oracle.minimize_binary_array(g, 21, 11))
+    # k = 32 is beyond the 32 candidate states the machines track: rejected, like w > k + 1
+    from sequencealigner_amd import capi
+    with pytest.raises(capi.SaError):
+        minimize.minimize_batch(seqs[:2], 32, 5)

@@ -192,3 +192,29 @@ def test_options_are_set_by_name_only():
         capi.set_option("force_i32", 0)
         capi.set_option("force_family", 0)
     assert lib.sa_align_kernel_name(ctypes.byref(b)) == b"lane_pk16"
+
+
+def test_command_line_surface_of_the_mapper():
+    """The option string and defaults of the mapper's main() (reference src/mapper.cpp:446-529, :467-471), its
+    index figures (:198-222) and report layouts, without touching the GPU."""
+    from sequencealigner_amd import cli
+    opt, rest = cli.parse_args([])
+    assert (opt["alignment_type"], opt["match"], opt["mismatch"], opt["gap"], opt["cigar"], opt["k"], opt["w"],
+            opt["threads"], opt["f"]) == (0, 1, -1, 0, False, 15, 5, 5, 0.001) and rest == []
+    # short -c takes an argument (option string "c:"), --cigar takes none; options may follow the file names
+    opt, rest = cli.parse_args(["-a", "2", "ref.fa", "-c", "reads.fq", "reads2.fq", "--gap=-2", "-k", "19x", "-n", "abc"])
+    assert rest == ["ref.fa", "reads2.fq"] and opt["cigar"] and opt["gap"] == -2
+    assert opt["k"] == 19 and opt["mismatch"] == 0      # atoi: leading digits, 0 without any
+    opt, rest = cli.parse_args(["--cigar", "a.fa", "b.fq", "--thread_num", "12", "--frequent", "0.01"])
+    assert opt["cigar"] and rest == ["a.fa", "b.fq"] and opt["threads"] == 12 and opt["f"] == 0.01
+    # (occurrences, value) pairs in increasing order: (1,5) (1,11) (2,9) (3,7); f = 0.3 -> index 1 from the top
+    assert cli.index_figures([5, 7, 7, 7, 9, 9, 11], 0.3) == (4, 2, 2)
+    assert cli.index_figures([5, 7, 7, 7, 9, 9, 11], 0.0) == (4, 2, 3)
+    lines = cli.help_text().splitlines()
+    assert len(lines) == 19 and all(len(x) == len(lines[0]) for x in lines)
+    assert lines[1].split("|")[1:5] == ["   command", " " * 19 + "explanation", "parameter ", "      default values"]
+    text = cli.stats_text({"count": 4, "total": 1100, "longest": 500, "longest_name": "c", "shortest": 100,
+                           "shortest_name": "b", "average": 275.0, "n50": 500})
+    assert "Average length: 275\n" in text and text.startswith("---------------Statistics---------------\n")
+    assert "Singleton Fraction of refence genome: 0.5\n" in cli.index_text(4, 2, 3)
+    assert "alignment score: 7\ntaget begin: 3\n" in cli.alignment_text("q", 10, "t", 12, 0, 1, -1, 0, 3, 7)
