@@ -320,7 +320,7 @@ def leg_nw_100k(lib, dev, steps, warmup, with_cpu):
                        "gap -1, full CIGAR (2.5 GB of direction bits)",
            "value": b.cells * steps / elapsed / 1e9, "unit": "GCUPS", "ms_per_step": elapsed / steps * 1e3,
            "steps": steps, "score": score, "cigar_rescores_to_score": ok,
-           "query_consumed": qmax, "roofline": roofline_of(b, typ, float(b.cells), steps, ms, cnt, "fill_wave_i32")}
+           "query_consumed": qmax, "roofline": roofline_of(b, typ, float(b.cells), steps, ms, cnt, "fill_wave_coop2<0")}
     if with_cpu:   # the full matrix would need 80 GB: the CPU checker's two-row scorer gives the score alone
         cpu_checker, _ = cpu_checker_lib()
         t0 = time.perf_counter()
@@ -446,6 +446,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the other alignment shapes")
     ap.add_argument("--legs", default="nw_1kx1k,sg_10kx11k,nw_100kx100k,pcie",
                     help="comma-separated legs to run besides the headline")
+    ap.add_argument("--leg-steps", type=int, default=0, help="timed steps of every leg (default: 5 / 2 / 3)")
     ap.add_argument("--sg-pairs", type=int, default=25_000, help="semi-global leg: pairs per GPU (one GPU)")
     ap.add_argument("--sg-total", type=int, default=200_000,
                     help="semi-global leg under --gpus N > 1: size of the fixed set that is split over the ranks")
@@ -519,15 +520,16 @@ def main():
             if "pcie" in legs_wanted and args.workload == "sw_150x300" and not args.no_cigar:
                 out["pcie"] = pcie_leg(lib, q, t, typ, 200_000)
             if "nw_1kx1k" in legs_wanted:
-                legs["nw_1kx1k"] = leg_nw_1k(lib, dev, 5, 2, threads, with_cpu)
+                legs["nw_1kx1k"] = leg_nw_1k(lib, dev, args.leg_steps or 5, 2 if not args.leg_steps else 1, threads,
+                                             with_cpu)
             if "sg_10kx11k" in legs_wanted:
-                legs["sg_10kx11k"] = leg_sg_10k(lib, dev, 2, 1, threads, with_cpu, args.sg_pairs)
+                legs["sg_10kx11k"] = leg_sg_10k(lib, dev, args.leg_steps or 2, 1, threads, with_cpu, args.sg_pairs)
             if "nw_100kx100k" in legs_wanted:
-                legs["nw_100kx100k"] = leg_nw_100k(lib, dev, 3, 1, with_cpu)
+                legs["nw_100kx100k"] = leg_nw_100k(lib, dev, args.leg_steps or 3, 1, with_cpu)
         if legs:
             out["legs"] = legs
         if not args.no_minimizers and not world.is_dist:
-            out["minimizers"] = minimizer_leg(dev, 3, threads, with_cpu)
+            out["minimizers"] = minimizer_leg(dev, args.leg_steps or 3, threads, with_cpu)
         print(json.dumps(out), flush=True)
     sdist.finalize(world)
     return out

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   bool live = valid, sets = false;
   uint32_t Mf = 1, Mc = 1;
   if (valid) {
-    if (F <= kWarm) {  // close to the sequence start: run the windows before the chunk exactly
+    // close to the sequence start (the warm-up would begin before k-mer k + 1, whose candidates reach back
+    // to position 0): run the windows before the chunk exactly
+    if (F <= kWarm + k + 2) {
       for (uint32_t b = 0; b < w + k - 1; ++b) m.push(M::feed1(s[b], other));
       m.first_window();
       if (F == 0) emit();
@@ -557,24 +559,26 @@ struct EmitArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
-  // one buffer, three uses: [0, 4096) grouped keys, [4096, 6144) bins, [6144, 10240) sorted keys; the triples are
-  // staged over the first two once the sort is done
-  __shared__ __attribute__((aligned(16))) uint32_t buf[5 * kSmallMax];
+  // one buffer, two uses: [0, 4096) grouped keys + [4096, 6144) bins while sorting, then the staged triples
+  __shared__ __attribute__((aligned(16))) uint32_t buf[3 * kSmallMax];
   __shared__ uint32_t lds[kThreads / 64];
-  __shared__ uint32_t s_seq;
+  __shared__ uint32_t dup_rank[64];  // ranks of keys that repeat their predecessor (few, if any)
+  __shared__ uint32_t s_seq, s_ndup;
   __shared__ uint64_t s_excl;
   uint64_t* grouped = reinterpret_cast<uint64_t*>(buf);
   uint32_t* bins = buf + 2 * kSmallMax;
-  uint64_t* sorted = reinterpret_cast<uint64_t*>(buf + 3 * kSmallMax);
   uint32_t* stage = buf;
   static_assert(kBins == kSmallMax, "LDS layout");
   const uint32_t tid = threadIdx.x;
   if (*a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
-  if (tid == 0) s_seq = atomicAdd(a.ticket, 1u);
+  if (tid == 0) {
+    s_seq = atomicAdd(a.ticket, 1u);
+    s_ndup = 0;
+  }
   __syncthreads();
   const uint32_t s = s_seq;
   if (s >= a.n) return;
-  const uint32_t begin = a.seg_begin[s], count = a.seg_end[s] - begin;  // count <= kSmallMax (checked by the host)
+  const uint32_t begin = a.seg_begin[s], count = a.seg_end[s] - begin;  // count <= kSmallMax (n_big == 0)
   constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
 #pragma unroll
   for (uint32_t e = 0; e < kBinsPer; ++e) bins[tid + e * kThreads] = 0;
@@ -611,37 +615,37 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
     if (i < count) grouped[atomicAdd(&bins[bin[e]], 1u)] = mine[e];
   }
   __syncthreads();
-  // bins[b] is now the end of bin b: rank every key among the keys of its bin
-  for (uint32_t p = tid; p < count; p += kThreads) {
-    const uint64_t key = grouped[p];
-    const uint32_t b = value_bin((uint32_t)(key >> a.key_shift), a.value_bits);
-    const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
-    uint32_t rank = 0;
-    for (uint32_t m = lo; m < hi; ++m) {
-      const uint64_t other = grouped[m];
-      rank += (other < key || (other == key && m < p)) ? 1u : 0u;
-    }
-    sorted[lo + rank] = key;
-  }
-  __syncthreads();
-  // distinct keys: thread t looks at the kPer consecutive sorted keys t*kPer ..
-  uint64_t k8[kPer];
-  uint32_t flags = 0;
-  {
-    const uint32_t first = tid * kPer;
-    uint64_t prev = (first > 0 && first < count) ? sorted[first - 1] : 0;
+  // bins[b] is now the end of bin b: rank every key among the keys of its bin; a key that has an equal key
+  // before it is a duplicate and is dropped
+  uint32_t rank[kPer];
 #pragma unroll
-    for (uint32_t e = 0; e < kPer; ++e) {
-      const uint32_t i = first + e;
-      if (i < count) {
-        k8[e] = sorted[i];
-        if (i == 0 || k8[e] != prev) flags |= 1u << e;
-        prev = k8[e];
+  for (uint32_t e = 0; e < kPer; ++e) {
+    const uint32_t p = tid + e * kThreads;
+    rank[e] = ~0u;
+    if (p < count) {
+      const uint64_t key = grouped[p];
+      mine[e] = key;
+      const uint32_t b = value_bin((uint32_t)(key >> a.key_shift), a.value_bits);
+      const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
+      uint32_t r = lo;
+      bool dup = false;
+      for (uint32_t m = lo; m < hi; ++m) {
+        const uint64_t other = grouped[m];
+        const bool same_before = other == key && m < p;
+        r += (other < key || same_before) ? 1u : 0u;
+        dup |= same_before;
       }
+      if (dup) {
+        const uint32_t at = atomicAdd(&s_ndup, 1u);
+        if (at < 64) dup_rank[at] = r;
+        r |= 0x80000000u;
+      }
+      rank[e] = r;
     }
   }
-  uint32_t uexcl;
-  const uint32_t uniq = block_sum(__builtin_popcount(flags), lds, &uexcl);  // (ends with a barrier)
+  __syncthreads();  // grouped / bins are free from here on
+  const uint32_t ndup = s_ndup;
+  const uint32_t uniq = count - ndup;
   // this sequence's place among all sequences: look back over the predecessors' counts
   if (tid < 64) {
     const uint32_t lane = tid;
@@ -687,16 +691,41 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
       }
     }
   }
-  // stage the triples (the grouped keys and the bins are no longer needed) and write them as one run
-  uint32_t r = uexcl;
+  // place of every distinct key among the distinct keys: its sorted rank minus the duplicates before it
+  uint32_t upos[kPer];
+  if (ndup <= 64) {
+#pragma unroll
+    for (uint32_t e = 0; e < kPer; ++e) {
+      uint32_t d = 0;
+      for (uint32_t x = 0; x < ndup; ++x) d += dup_rank[x] < rank[e] ? 1u : 0u;
+      upos[e] = rank[e] - d;
+    }
+  } else {  // many repeats (never seen on real sequences): mark the duplicates' ranks and count below each rank
+    uint32_t* is_dup = bins;
+#pragma unroll
+    for (uint32_t e = 0; e < kBinsPer; ++e) is_dup[tid + e * kThreads] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < kPer; ++e)
+      if (rank[e] != ~0u && (rank[e] & 0x80000000u)) is_dup[rank[e] & 0x7FFFFFFFu] = 1;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < kPer; ++e) {
+      uint32_t d = 0;
+      if (!(rank[e] & 0x80000000u))
+        for (uint32_t x = 0; x < rank[e]; ++x) d += is_dup[x];
+      upos[e] = rank[e] - d;
+    }
+    __syncthreads();
+  }
   const uint64_t low = (1ull << a.key_shift) - 1;
 #pragma unroll
   for (uint32_t e = 0; e < kPer; ++e) {
-    if (!((flags >> e) & 1u)) continue;
-    stage[3 * r] = (uint32_t)(k8[e] >> a.key_shift);
-    stage[3 * r + 1] = (uint32_t)((k8[e] & low) >> 1);
-    stage[3 * r + 2] = (uint32_t)(k8[e] & 1);
-    ++r;
+    if (rank[e] & 0x80000000u) continue;  // beyond the keys, or a duplicate
+    const uint32_t u = upos[e];
+    stage[3 * u] = (uint32_t)(mine[e] >> a.key_shift);
+    stage[3 * u + 1] = (uint32_t)((mine[e] & low) >> 1);
+    stage[3 * u + 2] = (uint32_t)(mine[e] & 1);
   }
   __syncthreads();
   const uint64_t first_out = s_excl;
@@ -791,8 +820,9 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   const uint64_t span = (uint64_t)k + w - 2;
   pl->capacity = total_len > span * n ? total_len - span * n : 1;  // total windows
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
-  // enough chunks to occupy the GPU: 1024 windows each, 256 when the batch is small
-  pl->chunk = (total_len / 1024 >= 65536) ? 1024 : 256;
+  // enough chunks to occupy the GPU: 256 windows each for small batches, 1024 or 2048 for large ones (a chunk
+  // pays 160 warm-up steps; measured on 1 Gbp of reads: 4.50 ms with 1024, 4.29 with 2048, 4.73 with 4096)
+  pl->chunk = (total_len / 2048 >= 65536) ? 2048 : (total_len / 1024 >= 65536) ? 1024 : 256;
   {  // test hook: any chunk length from 8 to 4096 windows
     const long v = options().min_chunk;
     if (v >= 8 && v <= 4096) pl->chunk = (uint32_t)v;

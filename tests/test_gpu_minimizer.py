@@ -100,7 +100,7 @@ def test_sortedness_and_uniqueness_property():
         assert r[:, 1].max() <= 10_000 - 15
 
 
-@pytest.mark.parametrize("chunk", ["24", "64", "1024"])
+@pytest.mark.parametrize("chunk", ["8", "24", "64", "1024"])
 def test_mixed_lengths_and_chunk_sizes_vs_oracle(oracle, chunk):
     """Sequences with more keys than the in-LDS sort takes (left to the segmented sort) next to short
     ones, constant and periodic stretches that keep the candidate sets from collapsing, and chunk
@@ -117,7 +117,7 @@ def _mixed_lengths(oracle, chunk, minimize, synth):
     rng = random.Random(5)
     seqs = [bytes(synth.genome(40_000, seed=81)),
             bytes(synth.genome(3_000, seed=82)) + b"A" * 5000 + bytes(synth.genome(9_000, seed=83)) + b"CG" * 3000,
-            b"ACGTTGCA" * 2500, b"T" * 30000, bytes(synth.genome(32, seed=84))]
+            b"ACGTTGCA" * 2500, b"ACGTTGCAAC" * 500, b"T" * 30000, bytes(synth.genome(32, seed=84))]
     seqs += [bytes(synth.genome(rng.randint(32, 12_000), seed=90 + i)) for i in range(40)]
     for k, w in ((15, 5), (4, 5), (16, 17), (2, 1)):
         res = minimize.minimize_batch(seqs, k, w)
@@ -190,3 +190,18 @@ def test_k_above_16_vs_oracle(oracle):
     from sequencealigner_amd import capi
     with pytest.raises(capi.SaError):
         minimize.minimize_batch(seqs[:2], 32, 5)
+
+
+def test_reads_with_many_repeated_keys_vs_oracle(oracle):
+    """The one-kernel sort + unique + output path of read batches keeps a short list of repeated keys and has a
+    second way for sequences with more than 64 of them: tiny chunks make every chunk boundary repeat a key."""
+    from sequencealigner_amd import capi, minimize, synth
+    seqs = [bytes(synth.genome(6000, seed=500 + i)) for i in range(40)] + [b"ACGTTGCAAC" * 500, b"G" * 4000]
+    capi.set_option("min_chunk", 8)
+    try:
+        for k, w in ((15, 5), (6, 7)):
+            res = minimize.minimize_batch(seqs, k, w)
+            for s, r in zip(seqs, res):
+                assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s))
+    finally:
+        capi.set_option("min_chunk", 0)
