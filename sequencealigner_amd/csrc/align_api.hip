@@ -110,11 +110,20 @@ bool lane_pk16_applicable(const sa_align_batch& b, int K, uint32_t* bias_out) {
 // Can the packed 16-bit wavefront kernel reproduce this batch exactly?  (Preconditions at the top of
 // align_wave_pk16.h; the matrix it sweeps is padded to whole strips of columns.)
 bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
-  if (b.type == SA_LOCAL) return false;
   const long match = b.match, mismatch = b.mismatch, gap = b.gap;
   if (gap > 0 || mismatch > match || match < gap) return false;
   const long Q = b.max_qlen, T = b.max_tlen;
   if (Q == 0 || T == 0) return false;
+  if (b.type == SA_LOCAL) {
+    // scores are kept times 16: values from min(gap, mismatch) (a candidate next to a zero) to the best score
+    // possible, plus the (match - gap) the diagonal candidate is formed with, in 11 bits
+    if (gap >= 0 || mismatch >= 0) return false;
+    const long bias = 1 - std::min(gap, mismatch);
+    const long hi = std::max(match, 0L) * std::min(Q, T);
+    if (hi + bias + (match - gap) + 1 > 0x7FF) return false;
+    *bias_out = (uint32_t)bias;
+    return true;
+  }
   const long strip = 64 * kWavePkCols;
   const long q_pad = (Q + strip - 1) / strip * strip;
   const long lo = (b.type == SA_GLOBAL ? gap * (q_pad + T) : gap * q_pad) + std::min(gap, std::min(mismatch, 0L));
@@ -419,24 +428,20 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
 
 template <int MODE>
 int launch_wave_pk16(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
-  if constexpr (MODE == SA_LOCAL) {
-    return fail(SA_ERR_ARGUMENT, "packed wavefront kernel chosen for Local");
-  } else {
+  {
+    Timed tm(stream, 1);
+    hipLaunchKernelGGL((fill_wave_pk16<MODE>), dim3((a.pairs_in_pass + 1) / 2), dim3(64), 0, stream, a,
+                       pl.bias);
+  }
+  SA_HIP_TRY(hipGetLastError());
+  if (need_traceback) {
     {
-      Timed tm(stream, 1);
-      hipLaunchKernelGGL((fill_wave_pk16<MODE>), dim3((a.pairs_in_pass + 1) / 2), dim3(64), 0, stream, a,
-                         pl.bias);
+      Timed tm(stream, 2);
+      hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
     }
     SA_HIP_TRY(hipGetLastError());
-    if (need_traceback) {
-      {
-        Timed tm(stream, 2);
-        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
-      }
-      SA_HIP_TRY(hipGetLastError());
-    }
-    return SA_OK;
   }
+  return SA_OK;
 }
 
 template <int MODE>

@@ -1,6 +1,6 @@
 // Wavefront DP fill (see align_wave_i32.h for the sweep) with packed 16-bit scores: TWO pairs per
-// wavefront, pair A in the low halves and pair B in the high halves of every register, Global and
-// Semiglobal only.  Number format as in align_lane_pk16.h: S(x) = x + BIAS with bit 15 of each half set,
+// wavefront, pair A in the low halves and pair B in the high halves of every register.
+// Number format as in align_lane_pk16.h: S(x) = (x + BIAS) << SH with bit 15 of each half set,
 // so plain 32-bit add/sub act as two independent 16-bit operations and unsigned packed max orders the
 // halves.  Per cell (both pairs): xor + packed min (symbols differ?), add, packed multiply-add (diagonal
 // candidate), two packed max, two packed subtractions whose sign bits are the direction flags (one
@@ -13,8 +13,16 @@
 // taken at its own last column / row.  One wavefront walks the strips of its two pairs one after the
 // other (the sequential mode of the 32-bit kernel; thousands of pairs per launch).
 //
+// Local keeps the scores times 16 (SH = 4; 0 otherwise): the four free bits of a cell's value take
+// 15 - (column within the lane), so one packed max per cell finds the leftmost maximum of the lane's row
+// segment for both pairs, and one strict packed compare per step keeps the first row that reached the
+// lane's best (src/alignment.cpp:203-207: the first strict maximum in row-major order).  Every strip's
+// candidate is merged into the lane's at the strip's end (equal score: the smaller row wins - a later
+// strip has larger columns), the lanes' candidates at the end of the sweep.  Cells of the padding never
+// win: each is strictly below a cell of the pair itself (a gap or mismatch away).
+//
 // Preconditions (checked on the host): gap <= 0, mismatch <= match, gap <= match, every value of the
-// padded matrix within the 15-bit window.
+// padded matrix within the 15-bit window (Local: gap < 0, mismatch < 0, an 11-bit window).
 #ifndef SA_ALIGN_WAVE_PK16_H
 #define SA_ALIGN_WAVE_PK16_H
 
@@ -46,8 +54,8 @@ struct WaveFmtPk16 {
 
 template <int MODE>
 __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias) {
-  static_assert(MODE != SA_LOCAL, "packed wavefront kernel: Global and Semiglobal only");
   constexpr int C = kWavePkCols;
+  constexpr int SH = (MODE == SA_LOCAL) ? 4 : 0;
   constexpr uint32_t STRIP = 64 * C;
   __shared__ uint32_t tring[256];  // target symbols of both pairs, index = position & 255
   const uint32_t lane = threadIdx.x;
@@ -69,15 +77,17 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
 
   // per pair: best last-column score (Semiglobal) / final score (Global), kept by the lane that owns
   // the pair's last column
+  // (Local: every lane's best cell so far - score, row, column)
   int bestA = 0, bestB = 0, finalA = 0, finalB = 0;
-  uint32_t biA = 0, biB = 0;
+  uint32_t biA = 0, biB = 0, brA = 0, brB = 0;
 
   if (Q != 0 && T != 0) {
     const uint32_t G = kGuard2;
-    auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v)) | G; };
-    const uint32_t gsub2 = rep2((uint32_t)(-gap));                               // |gap|
-    const uint32_t mg2 = rep2((uint32_t)(a.match - gap));                        // match - gap >= 0
-    const uint32_t negdelta2 = rep2((uint32_t)(a.mismatch - a.match) & 0xFFFFu);  // mod 2^16
+    auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v) << SH) | G; };
+    const uint32_t gsub2 = rep2((uint32_t)(-gap) << SH);                                  // |gap|
+    const uint32_t mg2 = rep2((uint32_t)(a.match - gap) << SH);                           // match - gap >= 0
+    const uint32_t negdelta2 = rep2(((uint32_t)(a.mismatch - a.match) << SH) & 0xFFFFu);  // mod 2^16
+    const uint32_t floor2 = SG(0);  // Local: a cell's score is at least 0
     const uint32_t one2 = 0x00010001u;
     const uint32_t nstrips_p = (Q + STRIP - 1) / STRIP;
     uint2* dirs = reinterpret_cast<uint2*>(a.dirs + (uint64_t)unit * a.dirs_unit_stride);
@@ -102,6 +112,9 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
       }
       uint32_t ldiag = SG(border_row0<MODE>((int)c0, gap) + gap);  // S(H[i-1][c0] + gap), lane's first row
       uint32_t lastcol = 0, bnext = 0, bout = 0;
+      // Local: this strip's best cell of the lane, both pairs - S(score) | 15 - column in the low bits of
+      // each half (the value of "no cell yet" is S(0)), and the rows they were found in
+      uint32_t skey = floor2, siA = 0, siB = 0;
       auto tsym = [&](uint32_t pos) -> uint32_t {  // both pairs' target symbols at a position
         const uint32_t sa = pos < TA ? (uint32_t)tA[pos] : kTargetPad;
         const uint32_t sb = pos < TB ? (uint32_t)tB[pos] : kTargetPad;
@@ -137,13 +150,15 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
             const uint32_t ne = pk_min_u16(tc ^ qc[k], one2);  // 1 where the symbols differ
             dc[k] = pk_mad_u16(ne, negdelta2, diag + mg2);
             mx[k] = pk_max_u16(dc[k], Hg[k]);
+            if (MODE == SA_LOCAL) mx[k] = pk_max_u16(mx[k], floor2);
           }
           // pass 2: the dependent chain along the row (max with the left candidate, then + gap), with the
           // flag work of the cell before interleaved so that the chain's latencies are covered.  Flags:
           // candidate - max is negative (bit 15 of the half set) exactly when the candidate is NOT the
           // maximum; one v_perm turns the four sign bits into four 0x00/0xFF bytes.
-          uint32_t left = recv, acc0 = 0, acc1 = 0;
+          uint32_t left = recv, acc0 = 0, acc1 = 0, rowkey = 0;
           auto flags = [&](int k, uint32_t lin) __attribute__((always_inline)) {
+            if (MODE == SA_LOCAL) rowkey = pk_max_u16(rowkey, mx[k] | rep2((uint32_t)(15 - k)));
             const uint32_t signs =
                 __builtin_amdgcn_perm(pk_sub_u16(dc[k], mx[k]), pk_sub_u16(lin, mx[k]), 0x0B0A0908u);
             if (k < 8)
@@ -167,8 +182,19 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
           __builtin_nontemporal_store(u32x2{acc0, acc1}, reinterpret_cast<u32x2*>(drow + (uint64_t)st * 64));
           ldiag = recv;
           lastcol = left;
+          if (MODE == SA_LOCAL) {
+            // a row replaces the strip's candidate only with a strictly larger score: with the low bits of
+            // the old key filled, an equal score never exceeds it
+            const uint32_t old = skey | 0x000F000Fu;
+            const uint32_t now = pk_max_u16(old, rowkey);
+            const uint32_t changed = now ^ old;
+            const bool upA = (changed & 0xFFFFu) != 0, upB = (changed >> 16) != 0;
+            skey = (upA ? now & 0x0000FFFFu : skey & 0x0000FFFFu) | (upB ? now & 0xFFFF0000u : skey & 0xFFFF0000u);
+            siA = upA ? i : siA;
+            siB = upB ? i : siB;
+          }
           // a pair's last column is in this strip; Global wants it on one step only, the pair's last row
-          if ((s == stripA || s == stripB) &&
+          if (MODE != SA_LOCAL && (s == stripA || s == stripB) &&
               (MODE != SA_GLOBAL || (s == stripA && st == TA + laneA) || (s == stripB && st == TB + laneB))) {
             uint32_t pick = 0;  // low half: pair A's column regA, high half: pair B's column regB
 #pragma unroll
@@ -223,13 +249,46 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
           for (uint32_t st = b0; st <= e; ++st) step(st, std::false_type{});
         }
       }
+      if (MODE == SA_LOCAL) {  // the strip's candidates against the lane's: higher score, then smaller row
+        const int scA = (int)((skey & 0x7FF0u) >> 4) - (int)bias, scB = (int)((skey >> 20) & 0x7FFu) - (int)bias;
+        if (scA > bestA || (scA == bestA && scA > 0 && siA < biA)) {
+          bestA = scA;
+          biA = siA;
+          brA = c0 + 16 - (skey & 15u);
+        }
+        if (scB > bestB || (scB == bestB && scB > 0 && siB < biB)) {
+          bestB = scB;
+          biB = siB;
+          brB = c0 + 16 - ((skey >> 16) & 15u);
+        }
+      }
     }
+    if (MODE == SA_LOCAL) {  // the lanes' candidates: highest score, smallest row, smallest column
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int obA = __shfl_xor(bestA, off), obB = __shfl_xor(bestB, off);
+        const uint32_t oiA = (uint32_t)__shfl_xor((int)biA, off), orA = (uint32_t)__shfl_xor((int)brA, off);
+        const uint32_t oiB = (uint32_t)__shfl_xor((int)biB, off), orB = (uint32_t)__shfl_xor((int)brB, off);
+        if (obA > bestA || (obA == bestA && (oiA < biA || (oiA == biA && orA < brA)))) {
+          bestA = obA;
+          biA = oiA;
+          brA = orA;
+        }
+        if (obB > bestB || (obB == bestB && (oiB < biB || (oiB == biB && orB < brB)))) {
+          bestB = obB;
+          biB = oiB;
+          brB = orB;
+        }
+      }
+    }
+    if (MODE != SA_LOCAL) {
     bestA = __builtin_amdgcn_readlane(bestA, laneA);
     biA = (uint32_t)__builtin_amdgcn_readlane((int)biA, laneA);
     finalA = __builtin_amdgcn_readlane(finalA, laneA);
     bestB = __builtin_amdgcn_readlane(bestB, laneB);
     biB = (uint32_t)__builtin_amdgcn_readlane((int)biB, laneB);
     finalB = __builtin_amdgcn_readlane(finalB, laneB);
+    }
   }
   if (lane != 0) return;
 #pragma unroll
@@ -238,9 +297,14 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
     const uint32_t pl = h ? plB : plA, p = h ? pB : pA;
     const uint32_t Qh = h ? QB : QA, Th = h ? TB : TA;
     const int best = h ? bestB : bestA, fin = h ? finalB : finalA;
-    uint32_t bi = h ? biB : biA;
+    uint32_t bi = h ? biB : biA, br = Qh;
     int score;
-    if (Qh == 0 || Th == 0) {  // no cells: the result is a border value
+    if (MODE == SA_LOCAL) {
+      const bool any = Qh != 0 && Th != 0 && best > 0;
+      score = any ? best : 0;
+      bi = any ? bi : 0;
+      br = any ? (h ? brB : brA) : 0;
+    } else if (Qh == 0 || Th == 0) {  // no cells: the result is a border value
       score = (MODE == SA_GLOBAL) ? (Th == 0 ? border_row0<MODE>((int)Qh, gap) : border_col0<MODE>((int)Th, gap))
                                   : border_row0<MODE>((int)Qh, gap);
       bi = (MODE == SA_GLOBAL) ? Th : 0;
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
     }
     a.score[p] = score;
     a.end_i[pl] = bi;
-    a.end_r[pl] = Qh;
+    a.end_r[pl] = br;
   }
 }
 

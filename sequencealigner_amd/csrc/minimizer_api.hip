@@ -820,9 +820,13 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   const uint64_t span = (uint64_t)k + w - 2;
   pl->capacity = total_len > span * n ? total_len - span * n : 1;  // total windows
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
-  // enough chunks to occupy the GPU: 256 windows each for small batches, 1024 or 2048 for large ones (a chunk
-  // pays 160 warm-up steps; measured on 1 Gbp of reads: 4.50 ms with 1024, 4.29 with 2048, 4.73 with 4096)
-  pl->chunk = (total_len / 2048 >= 65536) ? 2048 : (total_len / 1024 >= 65536) ? 1024 : 256;
+  // enough chunks to occupy the GPU: 1024 or 2048 windows each for large batches (a chunk pays 160 warm-up
+  // steps; measured on 1 Gbp of reads: 4.50 ms with 1024, 4.29 with 2048, 4.73 with 4096), 256 or 128 for
+  // small ones (one 4.6 Mbp sequence: 130 / 119 / 102 / 125 / 172 us with 32 / 64 / 128 / 256 / 512)
+  pl->chunk = (total_len / 2048 >= 65536)  ? 2048
+              : (total_len / 1024 >= 65536) ? 1024
+              : (total_len / 256 >= 65536)  ? 256
+                                            : 128;
   {  // test hook: any chunk length from 8 to 4096 windows
     const long v = options().min_chunk;
     if (v >= 8 && v <= 4096) pl->chunk = (uint32_t)v;

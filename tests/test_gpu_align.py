@@ -312,23 +312,26 @@ def test_local_ties_across_strips_vs_oracle(oracle):
             assert (int(s[0]), c[0], int(tb[0])) == want, fam
         finally:
             _force_family(None)
+    import torch
     rng = np.random.default_rng(808)
     two = np.frombuffer(b"AC", dtype=np.uint8)
-    qs = [two[rng.integers(0, 2, size=int(rng.integers(1500, 2500)))] for _ in range(300)]
-    ts = [two[rng.integers(0, 2, size=int(rng.integers(1500, 2500)))] for _ in range(300)]
-    qb, qo = synth.to_blob(qs)
-    tb_, to = synth.to_blob(ts)
-    for (m, x, g) in ((1, -1, -1), (1, -3, -3), (2, -1, -2)):
-        b = align.DeviceAlignBatch(qs, ts, 1, m, x, g)
-        assert b.kernel_name() == "wave_i32"
-        b.run()
-        import torch
-        torch.cuda.synchronize()
-        s, tbeg = oracle.align_batch(qb, qo, tb_, to, 1, m, x, g, True, 16)
-        assert np.array_equal(b.scores(), s)
-        assert np.array_equal(b.target_begins(), tbeg)      # the start row depends on the end cell chosen
-        for i in range(0, 300, 29):
-            assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), 1, m, x, g)[1]
+    # lengths beyond the packed wavefront kernel's 11-bit Local window, and (301 pairs: the last wavefront
+    # holds one pair) lengths within it for the schemes with match 1
+    for lo, hi, n in ((1500, 2500, 300), (1100, 1900, 301)):
+        qs = [two[rng.integers(0, 2, size=int(rng.integers(lo, hi)))] for _ in range(n)]
+        ts = [two[rng.integers(0, 2, size=int(rng.integers(lo, hi)))] for _ in range(n)]
+        qb, qo = synth.to_blob(qs)
+        tb_, to = synth.to_blob(ts)
+        for (m, x, g) in ((1, -1, -1), (1, -3, -3), (2, -1, -2)):
+            b = align.DeviceAlignBatch(qs, ts, 1, m, x, g)
+            assert b.kernel_name() == ("wave_pk16" if hi == 1900 and m == 1 else "wave_i32")
+            b.run()
+            torch.cuda.synchronize()
+            s, tbeg = oracle.align_batch(qb, qo, tb_, to, 1, m, x, g, True, 16)
+            assert np.array_equal(b.scores(), s)
+            assert np.array_equal(b.target_begins(), tbeg)      # the start row depends on the end cell chosen
+            for i in range(0, n, 29):
+                assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), 1, m, x, g)[1]
 
 
 def test_cooperative_single_long_pair_vs_oracle(oracle):

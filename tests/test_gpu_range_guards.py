@@ -1,6 +1,6 @@
 """Directed GPU tests at the range guards of the packed 16-bit kernels.  The dispatcher may use them only while
-every value the DP forms fits their score window (15 bits for Global / Semiglobal, 9 bits for Local's best-cell
-key); one base or one score unit beyond, it must fall back to the 32-bit kernels.  For each guard: a batch whose
+every value the DP forms fits their score window (15 bits for Global / Semiglobal; Local's best-cell key leaves
+9 bits in the lane kernel and 11 in the wavefront kernel); one base or one score unit beyond, it must fall back to the 32-bit kernels.  For each guard: a batch whose
 largest admissible value sits exactly at the window edge must run on the packed kernel and equal the CPU
 checker, and the batch one step beyond must run on the 32-bit kernel and equal it too.  Contents that reach the
 extremes: identical sequences (highest scores), sequences without a common symbol (lowest), related random ones."""
@@ -71,6 +71,10 @@ WAVE_CASES = [
     (0, (1, -3, -3), 2000, 8204, "T"),
     # Semiglobal 13/-3/-3, T = 2100: 3 * 2048 + 4 + 13 Q + 16 + 1 <= 32767
     (2, (13, -3, -3), 2046, 2100, "Q"),
+    # Local keeps scores times 16 in 15 bits.  1/-1/-1: bias 2, min(Q, T) + 2 + 2 + 1 <= 2047
+    (1, (1, -1, -1), 2042, 2100, "Q"),
+    # Local 2/-3/-2: bias 4, 2 min(Q, T) + 4 + 4 + 1 <= 2047
+    (1, (2, -3, -2), 1500, 1019, "T"),
 ]
 
 
