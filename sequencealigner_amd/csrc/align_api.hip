@@ -430,8 +430,13 @@ template <int MODE>
 int launch_wave_pk16(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
   {
     Timed tm(stream, 1);
+    // score tables inside the kernel (a wavefront whose sequences hold at most four distinct bytes): the
+    // entries (mismatch - gap) and (match - mismatch) << SH must be non-negative bytes
+    const int sh = MODE == SA_LOCAL ? 4 : 0;
+    const uint32_t tables = !options().no_tables && a.mismatch - a.gap >= 0 &&
+                            ((long)(a.mismatch - a.gap) << sh) <= 255 && ((long)(a.match - a.mismatch) << sh) <= 255;
     hipLaunchKernelGGL((fill_wave_pk16<MODE>), dim3((a.pairs_in_pass + 1) / 2), dim3(64), 0, stream, a,
-                       pl.bias);
+                       pl.bias, tables);
   }
   SA_HIP_TRY(hipGetLastError());
   if (need_traceback) {

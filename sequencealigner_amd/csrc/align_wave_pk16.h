@@ -21,6 +21,14 @@
 // strip has larger columns), the lanes' candidates at the end of the sweep.  Cells of the padding never
 // win: each is strictly below a cell of the pair itself (a gap or mismatch away).
 //
+// Substitution scores by table (the `tables` argument allows it: mismatch - gap >= 0 and (match - mismatch)
+// << SH within a byte): a wavefront first marks the byte values of its pairs' sequences in LDS; with at most
+// four of them it numbers them 0..3, keeps for every column a v_perm selector {code of pair A's query
+// symbol, zero, 4 + code of pair B's, zero} (a padding column selects the constant zero), and for every row
+// two words with (match - mismatch) in the byte of the pair's target symbol.  One v_perm then gives both
+// pairs' "symbols equal ? match - mismatch : 0" and one three-operand add forms the diagonal candidates:
+// 9 instructions for two cells instead of 11.  Other pairs compare the symbols as described above.
+//
 // Preconditions (checked on the host): gap <= 0, mismatch <= match, gap <= match, every value of the
 // padded matrix within the 15-bit window (Local: gap < 0, mismatch < 0, an 11-bit window).
 #ifndef SA_ALIGN_WAVE_PK16_H
@@ -53,11 +61,13 @@ struct WaveFmtPk16 {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias) {
+__global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias, uint32_t tables) {
   constexpr int C = kWavePkCols;
   constexpr int SH = (MODE == SA_LOCAL) ? 4 : 0;
   constexpr uint32_t STRIP = 64 * C;
-  __shared__ uint32_t tring[256];  // target symbols of both pairs, index = position & 255
+  // per target position (index = position & 255): both pairs' symbols in .x, or the pairs' table words
+  __shared__ uint2 tring[256];
+  __shared__ uint32_t seen[64];  // byte values that occur in the wavefront's sequences; then their codes
   const uint32_t lane = threadIdx.x;
   const uint32_t unit = blockIdx.x;
   const uint32_t plA = 2 * unit, plB = plA + 1;
@@ -99,15 +109,71 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
     const uint32_t laneA = (lastA % STRIP) / C, regA = lastA % C;
     const uint32_t laneB = (lastB % STRIP) / C, regB = lastB % C;
 
+    // Do the four sequences hold at most four distinct byte values?  Every lane marks the bytes of its share
+    // (aligned 8-byte words; the blobs are 8-byte aligned and readable up to 8 bytes past their end), then the
+    // values that occur are numbered in increasing order: seen[] becomes the byte -> code table.
+    bool use_tab = false;
+    const uint8_t* codes = reinterpret_cast<const uint8_t*>(seen);
+    if (tables) {
+      uint8_t* mark = reinterpret_cast<uint8_t*>(seen);
+      seen[lane] = 0;
+      __syncthreads();
+      auto scan = [&](const uint8_t* p, uint32_t len) {
+        const uint64_t b0 = (uint64_t)p, b1 = b0 + len;
+        for (uint64_t w = (b0 & ~7ull) + 8ull * lane; w < b1; w += 512) {
+          const uint64_t word = *reinterpret_cast<const uint64_t*>(w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (w + j >= b0 && w + j < b1) mark[(uint32_t)(word >> (8 * j)) & 0xFFu] = 1;
+        }
+      };
+      scan(qA, QA);
+      scan(tA, TA);
+      if (hasB) {
+        scan(qB, QB);
+        scan(tB, TB);
+      }
+      __syncthreads();
+      const uint32_t v = seen[lane];  // byte values 4 lane .. 4 lane + 3
+      uint32_t total = 0, rank = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t m = __ballot((v >> (8 * j)) & 1u);
+        total += (uint32_t)__builtin_popcountll(m);
+        rank += (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));  // values in the lanes below
+      }
+      uint32_t cv = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cv |= (rank & 0xFFu) << (8 * j);
+        rank += (v >> (8 * j)) & 1u;
+      }
+      use_tab = total <= 4;
+      __syncthreads();
+      seen[lane] = cv;
+      __syncthreads();
+    }
+    const uint32_t delta = (uint32_t)(a.match - a.mismatch) << SH;       // tables: a byte
+    const uint32_t exg2 = rep2((uint32_t)(a.mismatch - gap) << SH);      // tables: mismatch - gap >= 0
+
+    auto sweep = [&](auto tab_tag) __attribute__((always_inline)) {
+    constexpr bool TAB = decltype(tab_tag)::value;
     for (uint32_t s = 0; s < nstrips_p; ++s) {
       const uint32_t c0 = s * STRIP + lane * C;  // this lane's columns are r = c0+1 .. c0+C
       const bool last_strip = (s + 1 == nstrips_p);
-      uint32_t qc[C], Hg[C];  // query symbols (A | B << 16); S(H[i-1][column] + gap)
+      // query symbols (A | B << 16) or the columns' table selectors; S(H[i-1][column] + gap)
+      uint32_t qc[C], Hg[C];
 #pragma unroll
       for (int k = 0; k < C; ++k) {
-        const uint32_t sa = (c0 + k < QA) ? (uint32_t)qA[c0 + k] : kQueryPad;
-        const uint32_t sb = (c0 + k < QB) ? (uint32_t)qB[c0 + k] : kQueryPad;
-        qc[k] = sa | (sb << 16);
+        if (TAB) {  // bytes 0 / 2: which byte of pair A's / pair B's row word (0x0C: the constant zero)
+          const uint32_t ca = (c0 + k < QA) ? (uint32_t)codes[qA[c0 + k]] : 0x0Cu;
+          const uint32_t cb = (c0 + k < QB) ? 4u + (uint32_t)codes[qB[c0 + k]] : 0x0Cu;
+          qc[k] = ca | (cb << 16) | 0x0C000C00u;
+        } else {
+          const uint32_t sa = (c0 + k < QA) ? (uint32_t)qA[c0 + k] : kQueryPad;
+          const uint32_t sb = (c0 + k < QB) ? (uint32_t)qB[c0 + k] : kQueryPad;
+          qc[k] = sa | (sb << 16);
+        }
         Hg[k] = SG(border_row0<MODE>((int)(c0 + 1 + k), gap) + gap);
       }
       uint32_t ldiag = SG(border_row0<MODE>((int)c0, gap) + gap);  // S(H[i-1][c0] + gap), lane's first row
@@ -115,13 +181,19 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
       // Local: this strip's best cell of the lane, both pairs - S(score) | 15 - column in the low bits of
       // each half (the value of "no cell yet" is S(0)), and the rows they were found in
       uint32_t skey = floor2, siA = 0, siB = 0;
-      auto tsym = [&](uint32_t pos) -> uint32_t {  // both pairs' target symbols at a position
+      // both pairs' target symbols at a position; tables: per pair (match - mismatch) in the symbol's byte
+      auto tsym = [&](uint32_t pos) -> uint2 {
+        if (TAB) {
+          const uint32_t wa = pos < TA ? delta << (8 * (uint32_t)codes[tA[pos]]) : 0u;
+          const uint32_t wb = pos < TB ? delta << (8 * (uint32_t)codes[tB[pos]]) : 0u;
+          return make_uint2(wa, wb);
+        }
         const uint32_t sa = pos < TA ? (uint32_t)tA[pos] : kTargetPad;
         const uint32_t sb = pos < TB ? (uint32_t)tB[pos] : kTargetPad;
-        return sa | (sb << 16);
+        return make_uint2(sa | (sb << 16), 0u);
       };
       if (lane == 0) tring[0] = tsym(0);
-      uint32_t tc_next = tsym(0);  // lane 0's first row; the other lanes read theirs from the ring
+      uint2 tc_next = tsym(0);  // lane 0's first row; the other lanes read theirs from the ring
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing stays pending into the step loop
       const uint32_t steps = T + 63;
       uint2* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
@@ -133,8 +205,11 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
       auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const uint32_t j = (st - 1) & 63;
-        const uint32_t tc = tc_next;
-        tc_next = tring[(st - lane) & 255u];  // position of row st + 1 - lane
+        const uint2 tc = tc_next;
+        if (TAB)
+          tc_next = tring[(st - lane) & 255u];  // position of row st + 1 - lane
+        else
+          tc_next.x = tring[(st - lane) & 255u].x;
         const uint32_t from_left = (uint32_t)dpp_from_lane_below((int)lastcol);
         const uint32_t first = (s == 0) ? SG(border_col0<MODE>((int)st, gap) + gap)
                                         : (uint32_t)__builtin_amdgcn_readlane((int)bnext, j);
@@ -147,8 +222,12 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
 #pragma unroll
           for (int k = 0; k < C; ++k) {
             const uint32_t diag = k ? Hg[k - 1] : ldiag;
-            const uint32_t ne = pk_min_u16(tc ^ qc[k], one2);  // 1 where the symbols differ
-            dc[k] = pk_mad_u16(ne, negdelta2, diag + mg2);
+            if (TAB) {  // S(H + mismatch) + (symbols equal ? match - mismatch : 0), both pairs
+              dc[k] = diag + exg2 + __builtin_amdgcn_perm(tc.y, tc.x, qc[k]);
+            } else {
+              const uint32_t ne = pk_min_u16(tc.x ^ qc[k], one2);  // 1 where the symbols differ
+              dc[k] = pk_mad_u16(ne, negdelta2, diag + mg2);
+            }
             mx[k] = pk_max_u16(dc[k], Hg[k]);
             if (MODE == SA_LOCAL) mx[k] = pk_max_u16(mx[k], floor2);
           }
@@ -263,6 +342,11 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias)
         }
       }
     }
+    };
+    if (use_tab)
+      sweep(std::true_type{});
+    else
+      sweep(std::false_type{});
     if (MODE == SA_LOCAL) {  // the lanes' candidates: highest score, smallest row, smallest column
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {

@@ -401,3 +401,49 @@ def test_arbitrary_byte_alphabets_vs_oracle(oracle, family):
     for (m, x, g) in ((1, -1, -1), (2, -3, -2)):
         for typ in (0, 1, 2):
             _run_group(_oracle_cases(oracle, pairs, typ, m, x, g))
+
+
+def test_packed_wavefront_kernel_tables_per_wavefront(oracle):
+    """The packed wavefront kernel looks up substitution scores in tables when the sequences of a wavefront's two
+    pairs hold at most four distinct byte values, and compares symbols otherwise; the choice is made per wavefront.
+    One batch mixes: plain ACGT pairs, pairs with a fifth symbol in one sequence only (the partner pair of the
+    same wavefront then compares too), four-symbol sets of other bytes, two-symbol pairs; an odd number of pairs."""
+    import torch
+    from sequencealigner_amd import align, synth
+    rng = np.random.default_rng(4242)
+
+    def pair(alphabet, L):
+        t = np.frombuffer(alphabet, np.uint8)[rng.integers(0, len(alphabet), size=L + int(rng.integers(0, 80)))]
+        q = t[:L].copy()
+        flip = rng.random(L) < 0.08
+        q[flip] = np.frombuffer(alphabet, np.uint8)[rng.integers(0, len(alphabet), size=int(flip.sum()))]
+        return q, t
+
+    qs, ts = [], []
+    for i in range(41):
+        L = int(rng.integers(600, 1500))
+        kind = i % 5
+        q, t = pair([b"ACGT", b"ACGT", b"acgt", b"\x00\x01\xfe\xff", b"AC"][kind], L)
+        if kind == 1:      # a fifth symbol, in the target only
+            t = t.copy()
+            t[int(rng.integers(0, len(t)))] = ord("N")
+        qs.append(q)
+        ts.append(t)
+    qb, qo = synth.to_blob(qs)
+    tb_, to = synth.to_blob(ts)
+    for typ, (m, x, g) in ((0, (1, -1, -1)), (2, (2, -1, -2)), (1, (1, -1, -1)), (0, (2, -3, -2)), (2, (3, -1, -2))):
+        _force_family("wave")     # not the cooperative kernel, which a batch this small would get
+        try:
+            b = align.DeviceAlignBatch(qs, ts, typ, m, x, g)
+            assert b.kernel_name() == "wave_pk16", (typ, m, x, g)
+            b.run()
+            torch.cuda.synchronize()
+        finally:
+            _force_family(None)
+        s, tbeg = oracle.align_batch(qb, qo, tb_, to, typ, m, x, g, True, 16)
+        ok = np.ones(len(qs), bool) if typ == 0 else s > 0
+        assert np.array_equal(b.scores()[ok], s[ok]), (typ, m, x, g)
+        assert np.array_equal(b.target_begins()[ok], tbeg[ok]), (typ, m, x, g)
+        for i in range(0, len(qs), 3):
+            if ok[i]:
+                assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), typ, m, x, g)[1], (typ, i)
