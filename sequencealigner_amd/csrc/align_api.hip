@@ -164,7 +164,8 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
     const double strip_eff = max_q / (std::ceil(max_q / 1024.0) * 1024.0) * max_t / (max_t + 63.0);
     uint32_t unused_bias = 0;
     const bool wpk = !force_i32 && wave_pk16_applicable(b, &unused_bias);
-    const double wave_rate = std::min(b.n / (wpk ? 6144.0 : 2048.0), 1.0) * (wpk ? 5.0 : 3.0) * strip_eff;
+    const double wave_rate = std::min(b.n / (wpk ? 6144.0 : 2048.0), 1.0) *
+                             (wpk ? (b.type == SA_LOCAL ? 4.0 : 5.6) : 3.0) * strip_eff;
     want_wave = wave_rate > lane_rate;
   }
   if (b.type == SA_LOCAL &&
@@ -375,6 +376,8 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
 
 template <int MODE, int C, bool COOP>
 int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback) {
+  // score tables inside the kernel: (match - mismatch) must be a byte
+  const uint32_t tables = !options().no_tables && a.match >= a.mismatch && a.match - a.mismatch <= 255;
   {
     Timed tm(stream, 1);
     if (COOP) {
@@ -383,11 +386,11 @@ int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, 
       // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
       SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)a.pairs_in_pass * a.brow_unit_stride * 4, stream));
       SA_HIP_TRY(hipMemsetAsync(co.cand, 0xFF, cells * 12, stream));
-      hipLaunchKernelGGL((fill_wave_i32<MODE, C, true>), dim3((unsigned)cells), dim3(64), 0, stream, a, co);
+      hipLaunchKernelGGL((fill_wave_i32<MODE, C, true>), dim3((unsigned)cells), dim3(64), 0, stream, a, co, tables);
       if (MODE == SA_LOCAL)
         hipLaunchKernelGGL(wave_local_reduce, dim3((a.pairs_in_pass + 63) / 64), dim3(64), 0, stream, a, co);
     } else {
-      hipLaunchKernelGGL((fill_wave_i32<MODE, C, false>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a, co);
+      hipLaunchKernelGGL((fill_wave_i32<MODE, C, false>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a, co, tables);
     }
   }
   SA_HIP_TRY(hipGetLastError());
@@ -412,7 +415,9 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
       SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
       // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
       SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)a.pairs_in_pass * a.brow_unit_stride * 4, stream));
-      hipLaunchKernelGGL((fill_wave_coop2<MODE, C>), dim3((unsigned)waves), dim3(64), 0, stream, a, co);
+      // score tables inside the kernel: (match - mismatch) must be a byte
+      const uint32_t tables = !options().no_tables && a.match >= a.mismatch && a.match - a.mismatch <= 255;
+      hipLaunchKernelGGL((fill_wave_coop2<MODE, C>), dim3((unsigned)waves), dim3(64), 0, stream, a, co, tables);
     }
     SA_HIP_TRY(hipGetLastError());
     if (need_traceback) {

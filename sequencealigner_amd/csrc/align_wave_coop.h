@@ -63,8 +63,9 @@ __device__ __forceinline__ int dpp_shl1(int old, int v) {  // lane L <- lane L+1
 }
 
 template <int MODE, int C>
-__global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co) {
+__global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, uint32_t tables) {
   static_assert(MODE != SA_LOCAL, "Global and Semiglobal only");
+  __shared__ uint32_t seen[64];  // byte values of the strip's query columns and the target; then their codes
   constexpr uint32_t STRIP = 64 * C;
   constexpr uint32_t SPW = 16 / C;
   constexpr uint32_t B = kCoopBatch;
@@ -104,25 +105,50 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co) 
   const uint32_t lastc = Q - 1;
   const uint32_t lane_q = (lastc % STRIP) / C, reg_q = lastc % C;  // where column Q lives (last strip)
 
-  int qc[C], Hg[C];  // query symbols; H[i-1][column] + gap
+  // Substitution scores by table when the target and this strip's query columns hold at most four distinct
+  // byte values (`tables`: match - mismatch fits a byte): a column keeps the v_perm selector of its query
+  // symbol's code, a row the word with (match - mismatch) in the byte of its target symbol, so a cell's
+  // diagonal candidate is perm + three-operand add instead of compare + select + add.
+  bool use_tab = false;
+  const uint8_t* codes = reinterpret_cast<const uint8_t*>(seen);
+  if (tables) {
+    alphabet_clear(seen, lane);
+    const uint32_t q0 = s * STRIP;
+    alphabet_mark(seen, lane, q + q0, Q - q0 < STRIP ? Q - q0 : STRIP);
+    alphabet_mark(seen, lane, t, T);
+    use_tab = alphabet_number(seen, lane) <= 4;
+  }
+  const uint32_t delta = (uint32_t)(a.match - a.mismatch);
+
+  int best = 0, final_score = 0;  // Semiglobal: best last-column score; Global: H[T][Q]
+  uint32_t bi = 0;
+  auto sweep = [&](auto tab_tag) __attribute__((always_inline)) -> bool {
+  constexpr bool TAB = decltype(tab_tag)::value;
+  int qc[C], Hg[C];  // query symbols (tables: selectors); H[i-1][column] + gap
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    qc[k] = (c0 + k < Q) ? (int)q[c0 + k] : 512 + k;  // beyond the query: equals no byte
+    if (TAB)  // bytes 1-3 and a column beyond the query: the constant zero
+      qc[k] = (int)(0x0C0C0C00u | ((c0 + k < Q) ? (uint32_t)codes[q[c0 + k]] : 0x0Cu));
+    else
+      qc[k] = (c0 + k < Q) ? (int)q[c0 + k] : 512 + k;  // beyond the query: equals no byte
     Hg[k] = border_row0<MODE>((int)(c0 + 1 + k), gap) + gap;
   }
   int ldiag = border_row0<MODE>((int)c0, gap) + gap;  // H[i-1][c0] + gap for the lane's first row
   int lastcol = 0;                                    // H[i][c0 + C] + gap of the row just computed
-  int tc = 256;                                       // target symbol of the lane's current row
+  int tc = TAB ? 0 : 256;                             // target symbol (tables: row word) of the lane's current row
   int bout = 0;                                       // shift register of lane 63's results
   uint32_t acc = 0;                                   // direction flags of the last SPW steps
-  int best = 0, final_score = 0;                      // Semiglobal: best last-column score; Global: H[T][Q]
-  uint32_t bi = 0;
   const uint32_t steps = T + 63;
 
   // Inputs of lane 0 for the 32 steps of two batches, one per lane 0..31: the target symbol of row b0 + L and
   // the entry of the left boundary column for that row.
   auto want_row = [&](uint32_t b0) { return lane < kCoopFetch && b0 + lane <= T; };
   auto load_syms = [&](uint32_t b0) -> int { return want_row(b0) ? (int)t[b0 + lane - 1] : 256; };
+  // tables: symbols -> row words, once the loads have arrived
+  auto row_words = [&](int sym) -> int {
+    if (!TAB) return sym;
+    return sym < 256 ? (int)(delta << (8 * (uint32_t)codes[sym])) : 0;
+  };
   auto load_entries = [&](uint32_t b0) -> uint64_t {
     if (s == 0)  // column 0 of the matrix, tagged as if strip -1 had written it
       return ((uint64_t)s << 32) | (uint32_t)(border_col0<MODE>((int)(b0 + lane), gap) + gap);
@@ -166,7 +192,10 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co) 
 #pragma unroll
       for (int k = 0; k < C; ++k) {  // independent of each other: diagonal and "up" candidates
         const int diag = k ? Hg[k - 1] : ldiag;
-        dc[k] = diag + (tc == qc[k] ? em : ex);
+        if (TAB)
+          dc[k] = diag + ex + (int)__builtin_amdgcn_perm(0u, (uint32_t)tc, (uint32_t)qc[k]);
+        else
+          dc[k] = diag + (tc == qc[k] ? em : ex);
         mx[k] = max(dc[k], Hg[k]);
       }
       int left = recv;
@@ -233,7 +262,8 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co) 
 
   uint64_t e_cur = load_entries(1);
   int t_cur = load_syms(1);
-  if (!poll_entries(1, e_cur)) return;
+  if (!poll_entries(1, e_cur)) return false;
+  t_cur = row_words(t_cur);
   // up to one batch beyond the last step: the shift register needs it to deliver the last rows of the boundary
   for (uint32_t b0 = 1; b0 <= steps + B; b0 += kCoopFetch) {
     // fetch the inputs of the next two batches now, look at them after this pair of batches
@@ -244,18 +274,20 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co) 
     publish(b0);
     run_batch(b0 + B, std::integral_constant<uint32_t, 1>{}, bcur, t_cur);
     publish(b0 + B);
-    if (!poll_entries(b0 + kCoopFetch, e_next)) return;
+    if (!poll_entries(b0 + kCoopFetch, e_next)) return false;
     e_cur = e_next;
-    t_cur = t_next;
+    t_cur = row_words(t_next);
   }
-
-  if (!last_strip) return;  // only the strip with column Q knows the result
   {  // Global: a lane's registers keep the values of its last row, H[T][column] + gap
     uint32_t pick = 0;
 #pragma unroll
     for (int k = 0; k < C; ++k) pick |= (uint32_t)Hg[k] & ((uint32_t)k == reg_q ? ~0u : 0u);
     final_score = (int)pick - gap;
   }
+  return true;
+  };
+  if (!(use_tab ? sweep(std::true_type{}) : sweep(std::false_type{}))) return;  // gave up waiting
+  if (!last_strip) return;  // only the strip with column Q knows the result
   best = __builtin_amdgcn_readlane(best, lane_q);
   bi = (uint32_t)__builtin_amdgcn_readlane((int)bi, lane_q);
   final_score = __builtin_amdgcn_readlane(final_score, lane_q);

@@ -33,6 +33,48 @@
 
 namespace sa {
 
+// Which byte values occur in a wavefront's sequences?  `seen` is a 64-dword LDS array of the wavefront.
+// alphabet_clear, then alphabet_mark for every sequence (each lane marks the bytes of its share: aligned
+// 8-byte words - the blobs are 8-byte aligned and readable up to 8 bytes past their end), then alphabet_number
+// turns seen[] into the byte -> code table (values in increasing order from 0) and returns how many occur.
+// With at most four, a cell's substitution score is one v_perm_b32: the column keeps the selector "code of
+// its query symbol", the row a word with (match - mismatch) in the byte of its target symbol.
+__device__ __forceinline__ void alphabet_clear(uint32_t* seen, uint32_t lane) {
+  seen[lane] = 0;
+  __syncthreads();
+}
+__device__ __forceinline__ void alphabet_mark(uint32_t* seen, uint32_t lane, const uint8_t* p, uint32_t len) {
+  uint8_t* mark = reinterpret_cast<uint8_t*>(seen);
+  const uint64_t b0 = (uint64_t)p, b1 = b0 + len;
+  for (uint64_t w = (b0 & ~7ull) + 8ull * lane; w < b1; w += 512) {
+    const uint64_t word = *reinterpret_cast<const uint64_t*>(w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (w + j >= b0 && w + j < b1) mark[(uint32_t)(word >> (8 * j)) & 0xFFu] = 1;
+  }
+}
+__device__ __forceinline__ uint32_t alphabet_number(uint32_t* seen, uint32_t lane) {
+  __syncthreads();
+  const uint32_t v = seen[lane];  // byte values 4 lane .. 4 lane + 3
+  uint32_t total = 0, rank = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t m = __ballot((v >> (8 * j)) & 1u);
+    total += (uint32_t)__builtin_popcountll(m);
+    rank += (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));  // values in the lanes below
+  }
+  uint32_t cv = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    cv |= (rank & 0xFFu) << (8 * j);
+    rank += (v >> (8 * j)) & 1u;
+  }
+  __syncthreads();
+  seen[lane] = cv;
+  __syncthreads();
+  return total;
+}
+
 template <int C>
 struct WaveWord;
 template <>
@@ -89,7 +131,7 @@ __device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int diff) {
 // Local requires gap <= 0 and mismatch <= 0 here (checked on the host): cells of the padding columns
 // beyond the query then never exceed an earlier real cell, so they need no masking.
 template <int MODE, int C, bool COOP>
-__global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
+__global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co, uint32_t tables) {
   using word_t = typename WaveWord<C>::type;
   constexpr uint32_t STRIP = 64 * C;
   const uint32_t lane = threadIdx.x;
@@ -129,7 +171,20 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
   // (sub - gap) for equal / unequal symbols, opaque to the optimiser so that the select is not re-split
   const int em = __builtin_amdgcn_readfirstlane(a.match - gap);
   const int ex = __builtin_amdgcn_readfirstlane(a.mismatch - gap);
-  __shared__ uint8_t tring[256];
+  __shared__ uint32_t tring[256];  // per target position: the symbol, or the row's table word
+  __shared__ uint32_t seen[64];    // byte values of the wavefront's sequences; then their codes
+  // Substitution scores by table (see alphabet_number) when the wavefront's query columns and its target hold
+  // at most four distinct byte values; `tables`: match - mismatch fits a byte.
+  bool use_tab = false;
+  const uint8_t* codes = reinterpret_cast<const uint8_t*>(seen);
+  if (tables) {
+    alphabet_clear(seen, lane);
+    const uint32_t q0 = s_begin * STRIP, q1 = s_end * STRIP < Q ? s_end * STRIP : Q;
+    alphabet_mark(seen, lane, q + q0, q1 - q0);
+    alphabet_mark(seen, lane, t, T);
+    use_tab = alphabet_number(seen, lane) <= 4;
+  }
+  const uint32_t delta = (uint32_t)(a.match - a.mismatch);
   word_t* dirs = reinterpret_cast<word_t*>(a.dirs + (uint64_t)pl * a.dirs_unit_stride);
   // boundary columns: 64-bit entries {H + gap, tag}; COOP uses two of them alternately
   uint64_t* bbase = reinterpret_cast<uint64_t*>(a.brow + (uint64_t)pl * a.brow_unit_stride);
@@ -142,15 +197,24 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
   const uint32_t lastc = Q - 1;
   const uint32_t lane_q = (lastc % STRIP) / C, reg_q = lastc % C;  // where column Q lives
 
+  auto sweep = [&](auto tab_tag) __attribute__((always_inline)) -> bool {
+  constexpr bool TAB = decltype(tab_tag)::value;
+  auto tsym = [&](uint32_t pos) -> uint32_t {  // what the ring holds for a target position
+    if (pos >= T) return 0u;
+    return TAB ? delta << (8 * (uint32_t)codes[t[pos]]) : (uint32_t)t[pos];
+  };
   for (uint32_t s = s_begin; s < s_end; ++s) {
     const uint32_t c0 = s * STRIP + lane * C;  // this lane's columns are r = c0+1 .. c0+C
     const bool last_strip = (s + 1 == nstrips_p);
     const uint64_t* bin = bbase + ((s + 1) & 1) * bhalf;  // written by strip s-1 with tag s
     uint64_t* bout_p = bbase + (s & 1) * bhalf;           // written here with tag s+1
-    int qc[C], Hg[C];  // query symbols; H[i-1][column] + gap
+    int qc[C], Hg[C];  // query symbols (tables: v_perm selectors); H[i-1][column] + gap
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      qc[k] = (c0 + k < Q) ? (int)q[c0 + k] : 512 + k;  // beyond the query: equals no byte
+      if (TAB)  // bytes 1-3 and a column beyond the query: the constant zero
+        qc[k] = (int)(0x0C0C0C00u | ((c0 + k < Q) ? (uint32_t)codes[q[c0 + k]] : 0x0Cu));
+      else
+        qc[k] = (c0 + k < Q) ? (int)q[c0 + k] : 512 + k;  // beyond the query: equals no byte
       Hg[k] = border_row0<MODE>((int)(c0 + 1 + k), gap) + gap;
     }
     int ldiag = border_row0<MODE>((int)c0, gap) + gap;  // H[i-1][c0] + gap for the lane's first row
@@ -160,8 +224,8 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
     // steps; a lane reads the symbol of its next row one step ahead.  Inside the step loop nothing is
     // left pending on the memory counter between the 64-step batches: a wait on it would also wait for
     // the step's own stores.
-    if (lane == 0) tring[0] = t[0];
-    int tc_next = (int)t[0];  // lane 0's first row; the other lanes read theirs from the ring
+    if (lane == 0) tring[0] = tsym(0);
+    int tc_next = (int)tsym(0);  // lane 0's first row; the other lanes read theirs from the ring
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above and the query symbols
     const uint32_t steps = T + 63;
     word_t* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
@@ -189,7 +253,10 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
 #pragma unroll
         for (int k = 0; k < C; ++k) {
           const int diag = k ? Hg[k - 1] : ldiag;
-          dc[k] = diag + (tc == qc[k] ? em : ex);
+          if (TAB)
+            dc[k] = diag + ex + (int)__builtin_amdgcn_perm(0u, (uint32_t)tc, (uint32_t)qc[k]);
+          else
+            dc[k] = diag + (tc == qc[k] ? em : ex);
           mx[k] = (MODE == SA_LOCAL) ? max3i(dc[k], Hg[k], 0) : max(dc[k], Hg[k]);
         }
         // pass 2: the dependent chain along the row (max with the left candidate, then + gap), with the
@@ -254,7 +321,7 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
     for (uint32_t b0 = 1; b0 <= steps; b0 += 64) {  // batches of 64 steps
       {  // target positions b0 .. b0+63
         const uint32_t pos = b0 + lane;
-        tring[pos & 255u] = pos < T ? t[pos] : (uint8_t)0;
+        tring[pos & 255u] = tsym(pos);
       }
       if (s > 0) {  // rows b0 .. b0+63 of the previous strip's last column
         const uint32_t row = b0 + lane;
@@ -269,7 +336,7 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
               ((polls & 1023u) == 1023u &&
                __hip_atomic_load(co.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+            return false;
           }
         }
         bnext = (int)(uint32_t)e;
@@ -287,6 +354,9 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co) {
       }
     }
   }
+  return true;
+  };
+  if (!(use_tab ? sweep(std::true_type{}) : sweep(std::false_type{}))) return;  // gave up waiting
 
   // combine the lanes' candidates
   if (MODE == SA_LOCAL) {

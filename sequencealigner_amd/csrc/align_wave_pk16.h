@@ -109,49 +109,18 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
     const uint32_t laneA = (lastA % STRIP) / C, regA = lastA % C;
     const uint32_t laneB = (lastB % STRIP) / C, regB = lastB % C;
 
-    // Do the four sequences hold at most four distinct byte values?  Every lane marks the bytes of its share
-    // (aligned 8-byte words; the blobs are 8-byte aligned and readable up to 8 bytes past their end), then the
-    // values that occur are numbered in increasing order: seen[] becomes the byte -> code table.
+    // Do the four sequences hold at most four distinct byte values?  (seen[] becomes the byte -> code table.)
     bool use_tab = false;
     const uint8_t* codes = reinterpret_cast<const uint8_t*>(seen);
     if (tables) {
-      uint8_t* mark = reinterpret_cast<uint8_t*>(seen);
-      seen[lane] = 0;
-      __syncthreads();
-      auto scan = [&](const uint8_t* p, uint32_t len) {
-        const uint64_t b0 = (uint64_t)p, b1 = b0 + len;
-        for (uint64_t w = (b0 & ~7ull) + 8ull * lane; w < b1; w += 512) {
-          const uint64_t word = *reinterpret_cast<const uint64_t*>(w);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (w + j >= b0 && w + j < b1) mark[(uint32_t)(word >> (8 * j)) & 0xFFu] = 1;
-        }
-      };
-      scan(qA, QA);
-      scan(tA, TA);
+      alphabet_clear(seen, lane);
+      alphabet_mark(seen, lane, qA, QA);
+      alphabet_mark(seen, lane, tA, TA);
       if (hasB) {
-        scan(qB, QB);
-        scan(tB, TB);
+        alphabet_mark(seen, lane, qB, QB);
+        alphabet_mark(seen, lane, tB, TB);
       }
-      __syncthreads();
-      const uint32_t v = seen[lane];  // byte values 4 lane .. 4 lane + 3
-      uint32_t total = 0, rank = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint64_t m = __ballot((v >> (8 * j)) & 1u);
-        total += (uint32_t)__builtin_popcountll(m);
-        rank += (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));  // values in the lanes below
-      }
-      uint32_t cv = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        cv |= (rank & 0xFFu) << (8 * j);
-        rank += (v >> (8 * j)) & 1u;
-      }
-      use_tab = total <= 4;
-      __syncthreads();
-      seen[lane] = cv;
-      __syncthreads();
+      use_tab = alphabet_number(seen, lane) <= 4;
     }
     const uint32_t delta = (uint32_t)(a.match - a.mismatch) << SH;       // tables: a byte
     const uint32_t exg2 = rep2((uint32_t)(a.mismatch - gap) << SH);      // tables: mismatch - gap >= 0

@@ -35,8 +35,8 @@ def test_static_scratch_entry_point_equals_workspace_entry_point(oracle):
     lib = capi.lib()
     scratch = lib.sa_align_static_scratch_bytes()
     assert scratch == 64 << 20
-    # call 1: 12 000 Local pairs of the benchmark shape - the packed lane kernel, more than one pass of the array
-    q, t = synth.pairs_short_read_window(12_000, seed=31)
+    # call 1: 16 000 Local pairs of the benchmark shape - the packed lane kernel, more than one pass of the array
+    q, t = synth.pairs_short_read_window(16_000, seed=31)
     big = align.DeviceAlignBatch(q, t, 1, 1, -1, -1, workspace_bytes=1 << 30)
     assert big.kernel_name() == "lane_pk16"
     mn = C.c_size_t(0)
@@ -44,7 +44,7 @@ def test_static_scratch_entry_point_equals_workspace_entry_point(oracle):
     want, got = _both_ways(big)
     for w, g in zip(want, got):
         assert np.array_equal(w, g)
-    for i in range(0, 12_000, 1201):   # and the workspace path is itself checked against the CPU checker
+    for i in range(0, 16_000, 1601):   # and the workspace path is itself checked against the CPU checker
         assert (int(want[0][i]), big.cigars([i])[0], int(want[1][i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
     # call 2, right after it on the same array, smaller: 60 Global pairs on the packed wavefront kernel
     q2, t2 = synth.pairs_global_1k(60, seed=32, length=700)
