@@ -35,6 +35,27 @@ __device__ __forceinline__ uint64_t load8(const uint8_t* p) {  // any alignment
   return *reinterpret_cast<const uint64_t*>(p);
 }
 
+// The bookkeeping of a call on a single sequence in one launch: chunk and window counts with their (trivial)
+// prefix sums, counters and status cleared.
+__global__ void min_plan_single(const uint64_t* off, uint32_t k, uint32_t w, uint32_t chunk, uint32_t* nchunks,
+                                uint32_t* chunk_base, uint32_t* windows, uint32_t* wbase, uint32_t* counter,
+                                int* status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t len = (uint32_t)(off[1] - off[0]);
+  const uint32_t win = len >= k + w - 1 ? len - (k + w - 1) + 1 : 0;
+  const uint32_t nc = (win + chunk - 1) / chunk;
+  nchunks[0] = nc;
+  nchunks[1] = 0;
+  chunk_base[0] = 0;
+  chunk_base[1] = nc;
+  windows[0] = win;
+  windows[1] = 0;
+  wbase[0] = 0;
+  wbase[1] = win;
+  counter[0] = counter[1] = counter[2] = counter[3] = 0;  // keys, unresolved chunks, long sequences, other bytes
+  if (status) *status = 0;
+}
+
 // Writes the keys the lanes of a wave hold in LDS to their sequences' key ranges.  Lanes are ordered by
 // chunk, so lanes of one sequence are neighbours: the first lane of each run reserves the run's total
 // with one atomic on the sequence's counter.  Must be called by all lanes of the wave.
@@ -556,6 +577,16 @@ struct EmitArgs {
   uint32_t* out;
   uint64_t* out_off;
   int* status;
+  // buckets != 0: the segments are the value-ordered buckets of ONE sequence (bucket_plan): keys are binned
+  // linearly between the bucket's lowest and highest possible key, empty buckets only pass the count on, and
+  // out_off gets the sequence's two entries
+  uint32_t buckets;
+  const uint32_t* nseg_used;  // buckets in use (device side); the launch covers a.n >= that many
+  uint32_t fine_shift;
+  const uint32_t* seg_lof;    // first fine bin of the bucket, one past its last
+  const uint32_t* seg_hif;
+  const uint64_t* seg_lokey;  // set by bucket_split for the slices of an oversized bucket (seg_hif == 0 there)
+  const uint64_t* seg_span;
 };
 
 __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
@@ -565,21 +596,49 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   __shared__ uint32_t dup_rank[64];  // ranks of keys that repeat their predecessor (few, if any)
   __shared__ uint32_t s_seq, s_ndup;
   __shared__ uint64_t s_excl;
+  __shared__ uint64_t lb_sum[kThreads / 64];   // look-back: per wave, the counts it may add
+  __shared__ uint32_t lb_flag[kThreads / 64];  //   bit 0: usable, bit 1: ends at a prefix
   uint64_t* grouped = reinterpret_cast<uint64_t*>(buf);
   uint32_t* bins = buf + 2 * kSmallMax;
   uint32_t* stage = buf;
   static_assert(kBins == kSmallMax, "LDS layout");
   const uint32_t tid = threadIdx.x;
-  if (*a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
+  if (!a.buckets && *a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
   if (tid == 0) {
     s_seq = atomicAdd(a.ticket, 1u);
     s_ndup = 0;
   }
   __syncthreads();
   const uint32_t s = s_seq;
-  if (s >= a.n) return;
-  const uint32_t begin = a.seg_begin[s], count = a.seg_end[s] - begin;  // count <= kSmallMax (n_big == 0)
+  const uint32_t nsegs = a.buckets ? *a.nseg_used : a.n;
+  if (s >= nsegs) return;
+  const uint32_t begin = a.seg_begin[s];
+  uint32_t count = a.seg_end[s] - begin;  // <= kSmallMax: n_big == 0, bucket_split
+  if (count > kSmallMax) {                // never expected: fail the call rather than overrun the buffers
+    if (tid == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
+    count = kSmallMax;
+  }
   constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
+  // the bin of a key: reads - a function of the value; buckets - linear between the bucket's bounds
+  uint64_t lokey = 0;
+  uint32_t bshift = 0;
+  if (a.buckets && count) {
+    uint64_t span;
+    if (a.seg_hif[s]) {
+      lokey = (uint64_t)a.seg_lof[s] << a.fine_shift;
+      span = (uint64_t)(a.seg_hif[s] - a.seg_lof[s]) << a.fine_shift;
+    } else {
+      lokey = a.seg_lokey[s];
+      span = a.seg_span[s];
+    }
+    const uint32_t bits = span > 1 ? 64u - (uint32_t)__builtin_clzll(span - 1) : 0u;
+    bshift = bits > 11 ? bits - 11 : 0;
+  }
+  auto bin_of = [&](uint64_t key) -> uint32_t {
+    if (!a.buckets) return value_bin((uint32_t)(key >> a.key_shift), a.value_bits);
+    const uint64_t b = (key - lokey) >> bshift;
+    return b < kBins ? (uint32_t)b : kBins - 1;
+  };
 #pragma unroll
   for (uint32_t e = 0; e < kBinsPer; ++e) bins[tid + e * kThreads] = 0;
   __syncthreads();
@@ -590,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
     const uint32_t i = tid + e * kThreads;
     if (i < count) {
       mine[e] = a.keys[begin + i];
-      bin[e] = value_bin((uint32_t)(mine[e] >> a.key_shift), a.value_bits);
+      bin[e] = bin_of(mine[e]);
       atomicAdd(&bins[bin[e]], 1u);
     }
   }
@@ -625,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
     if (p < count) {
       const uint64_t key = grouped[p];
       mine[e] = key;
-      const uint32_t b = value_bin((uint32_t)(key >> a.key_shift), a.value_bits);
+      const uint32_t b = bin_of(key);
       const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
       uint32_t r = lo;
       bool dup = false;
@@ -646,8 +705,9 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   __syncthreads();  // grouped / bins are free from here on
   const uint32_t ndup = s_ndup;
   const uint32_t uniq = count - ndup;
-  // this sequence's place among all sequences: look back over the predecessors' counts
-  if (tid < 64) {
+  // this sequence's place among all sequences: look back over the predecessors' counts.  Reads: one wave,
+  // 64 predecessors at a time (blocks finish at different times, most find a prefix within a window or two).
+  if (!a.buckets && tid < 64) {
     const uint32_t lane = tid;
     if (lane == 0)
       __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
@@ -687,6 +747,68 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
       a.out_off[s] = before;
       if (s + 1 == a.n) {
         a.out_off[a.n] = before + uniq;
+        if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
+      }
+    }
+  }
+  // Buckets of one sequence: all blocks run at once and finish together, nobody has a prefix yet: 256
+  // predecessors at a time (wave v
+  // takes the 64 predecessors from top - 64 v downwards); whole waves are used up in order until one meets a
+  // predecessor that already carries its prefix, or one whose predecessors have not all published yet
+  if (a.buckets) {
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    if (tid == 0)
+      __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t before = 0;
+    int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
+    uint32_t polls = 0;
+    bool failed = false;
+    while (top >= 0) {
+      const int64_t idx = top - (int64_t)(wv * 64 + lane);
+      uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
+      if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t ready = __ballot((st >> 62) != 0);
+      const uint64_t final = __ballot((st >> 62) == 2);
+      // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the wave's
+      // window has no prefix and all 64 are ready)
+      const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
+      const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
+      uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) {
+        lb_sum[wv] = v;
+        lb_flag[wv] = ((ready & need) == need ? 1u : 0u) | (final ? 2u : 0u);
+      }
+      __syncthreads();
+      uint32_t used = 0;
+      bool done = false;
+      for (uint32_t x = 0; x < kThreads / 64 && !done; ++x) {
+        if (!(lb_flag[x] & 1u)) break;
+        before += lb_sum[x];
+        ++used;
+        done = (lb_flag[x] & 2u) != 0;
+      }
+      __syncthreads();
+      if (done) break;
+      top -= 64 * (int64_t)used;
+      if (used < kThreads / 64) {  // a wave's predecessors have not all published their counts yet
+        __builtin_amdgcn_s_sleep(1);
+        if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
+          failed = true;
+          break;
+        }
+      }
+    }
+    if (tid == 0) {
+      if (failed && a.status) atomicMax(a.status, SA_ERR_HIP);
+      if (s != 0)
+        __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = before;
+      if (!a.buckets || s == 0) a.out_off[s] = before;
+      if (s + 1 == nsegs) {
+        a.out_off[a.buckets ? 1 : a.n] = before + uniq;
         if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
       }
     }
@@ -733,6 +855,174 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   const uint32_t dwords = 3 * (uint32_t)(uniq < room ? uniq : room);
   uint32_t* dst = a.out + 3 * first_out;
   for (uint32_t x = tid; x < dwords; x += kThreads) dst[x] = stage[x];
+}
+
+// ---- one long sequence: its keys are cut into value-ordered buckets of about kBucketKeys keys, which
+// sort_emit_small then sorts, de-duplicates and writes like the reads of a batch - five launches instead of a
+// device-wide radix sort's twenty-odd, which is what a call on a single genome-sized sequence costs.
+//   bucket_hist     counts the keys per fine bin (the top kFineBits bits of the key's significant bits)
+//   bucket_plan     one block: exclusive prefix P of the counts (left in place as the scatter's cursors);
+//                   bucket of a fine bin = P >> 10, so buckets are runs of whole fine bins and hold at most
+//                   kBucketKeys keys plus one fine bin; writes every bucket's key range and fine-bin range
+//   bucket_scatter  moves every key to its fine bin's range (order inside a bin is arbitrary)
+//   bucket_split    only for a bucket beyond kSmallMax keys (one fine bin that holds thousands of keys: a value
+//                   repeated at thousands of positions): sorts it in place in global memory (bitonic network,
+//                   one block) and hands its slices to the bucket numbers its length left unused
+constexpr uint32_t kFineBits = 16, kFine = 1u << kFineBits;
+constexpr uint32_t kBucketShift = 10, kBucketKeys = 1u << kBucketShift;
+constexpr uint32_t kNoBin = 0xFFFFFFFFu;
+// where fine bin f's counter lives: transposed, so that bucket_plan, whose thread t owns the bins
+// t * 256 .. t * 256 + 255, reads and writes the array in coalesced lines
+__device__ __forceinline__ uint32_t fine_slot(uint32_t f) { return ((f & 255u) << 8) | (f >> 8); }
+
+struct BucketArgs {
+  const uint64_t* keys;     // the sequence's keys as min_run left them
+  uint64_t* grouped;        // the same keys, grouped by fine bin
+  const uint32_t* count;    // number of keys (device side)
+  uint32_t fine_shift;
+  uint32_t* hist;           // kFine counters, zeroed; after bucket_plan: exclusive prefix / cursors
+  uint32_t nseg;            // bucket numbers 0 .. nseg - 1 (more than the keys can fill)
+  uint32_t* nseg_used;      // bucket numbers the keys of this call reach: (count >> kBucketShift) + 1
+  uint32_t* seg_begin;      // all zeroed before bucket_plan
+  uint32_t* seg_end;
+  uint32_t* seg_lof;
+  uint32_t* seg_hif;
+  uint64_t* seg_lokey;
+  uint64_t* seg_span;
+};
+
+__global__ __launch_bounds__(kThreads) void bucket_hist(BucketArgs a) {
+  const uint32_t n = *a.count;
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+    atomicAdd(&a.hist[fine_slot((uint32_t)(a.keys[i] >> a.fine_shift))], 1u);
+}
+
+__global__ __launch_bounds__(kThreads) void bucket_plan(BucketArgs a) {
+  __shared__ uint32_t lds[kThreads / 64];
+  __shared__ uint32_t last_start[kThreads], last_bin[kThreads];
+  constexpr uint32_t kPer = kFine / kThreads;
+  static_assert(kPer == 256 && kThreads == 256, "fine_slot's transposition");
+  const uint32_t tid = threadIdx.x, base = tid * kPer;
+  // thread t owns the fine bins base .. base + 255, stored at e * 256 + t
+  uint32_t sum = 0, lb = kNoBin, ls = 0;
+#pragma unroll 16
+  for (uint32_t e = 0; e < kPer; ++e) {
+    const uint32_t c = a.hist[e * kThreads + tid];
+    if (c) {
+      lb = base + e;
+      ls = sum;  // (relative to the thread's first key)
+    }
+    sum += c;
+  }
+  uint32_t excl;
+  const uint32_t total = block_sum(sum, lds, &excl);
+  last_start[tid] = excl + ls;  // start of the thread's last non-empty fine bin, for the threads after it
+  last_bin[tid] = lb;
+  __syncthreads();
+  uint32_t prev = kNoBin, prev_start = 0;  // the non-empty fine bin before this thread's first one
+  for (int t = (int)tid - 1; t >= 0 && prev == kNoBin; --t) {
+    prev = last_bin[t];
+    prev_start = last_start[t];
+  }
+  uint32_t P = excl;
+  for (uint32_t e0 = 0; e0 < kPer; e0 += 32) {  // 32 counters at a time: loads first, then the stores
+    uint32_t cs[32];
+#pragma unroll
+    for (uint32_t x = 0; x < 32; ++x) cs[x] = a.hist[(e0 + x) * kThreads + tid];
+#pragma unroll
+    for (uint32_t x = 0; x < 32; ++x) {
+      const uint32_t f = base + e0 + x;
+      const uint32_t c = cs[x];
+      a.hist[(e0 + x) * kThreads + tid] = P;
+      if (c) {
+        const uint32_t id = P >> kBucketShift;
+        if (prev == kNoBin || (prev_start >> kBucketShift) != id) {  // first fine bin of bucket id
+          a.seg_begin[id] = P;
+          a.seg_lof[id] = f;
+          if (prev != kNoBin) {
+            a.seg_end[prev_start >> kBucketShift] = P;
+            a.seg_hif[prev_start >> kBucketShift] = prev + 1;
+          }
+        }
+        prev = f;
+        prev_start = P;
+      }
+      P += c;
+    }
+  }
+  // the last bucket ends with the keys
+  bool later = false;
+  for (uint32_t t = tid + 1; t < kThreads; ++t) later |= last_bin[t] != kNoBin;
+  if (lb != kNoBin && !later) {
+    a.seg_end[prev_start >> kBucketShift] = total;
+    a.seg_hif[prev_start >> kBucketShift] = prev + 1;
+  }
+  if (tid == 0) *a.nseg_used = (total >> kBucketShift) + 1;
+}
+
+__global__ __launch_bounds__(kThreads) void bucket_scatter(BucketArgs a) {
+  const uint32_t n = *a.count;
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    const uint64_t key = a.keys[i];
+    a.grouped[atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u)] = key;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bucket_split(BucketArgs a) {
+  const uint32_t id0 = blockIdx.x, tid = threadIdx.x;
+  if (id0 >= *a.nseg_used) return;
+  const uint32_t begin = a.seg_begin[id0], end = a.seg_end[id0], n = end - begin;
+  if (n <= kSmallMax) return;
+  uint64_t* v = a.grouped + begin;
+  // bitonic sorting network in which every comparison puts the smaller key first; positions beyond n count as
+  // keys larger than any, so comparisons with them never swap
+  uint32_t np = 1;
+  while (np < n) np <<= 1;
+  for (uint32_t k = 2; k <= np; k <<= 1) {
+    for (uint32_t x = tid; x < np / 2; x += kThreads) {  // first step of a merge: mirror pairs
+      const uint32_t blk = x / (k / 2), off = x % (k / 2);
+      const uint32_t i = blk * k + off, j = blk * k + k - 1 - off;
+      if (j < n) {
+        const uint64_t vi = v[i], vj = v[j];
+        if (vi > vj) {
+          v[i] = vj;
+          v[j] = vi;
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t d = k / 4; d > 0; d >>= 1) {
+      for (uint32_t x = tid; x < np / 2; x += kThreads) {
+        const uint32_t i = 2 * d * (x / d) + x % d, j = i + d;
+        if (j < n) {
+          const uint64_t vi = v[i], vj = v[j];
+          if (vi > vj) {
+            v[i] = vj;
+            v[j] = vi;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // The bucket's keys start in block id0 of kBucketKeys key positions and the next bucket's in block
+  // end >> kBucketShift: the numbers in between belong to nobody.  Equal slices for them, every cut moved
+  // forward past keys equal to the one before it (equal keys must meet in one slice to be de-duplicated).
+  if (tid == 0) {
+    const uint32_t avail = (end >> kBucketShift) - id0;  // >= 2
+    uint32_t cut = 0;
+    for (uint32_t m = 0; m < avail; ++m) {
+      uint32_t next = m + 1 == avail ? n : (uint32_t)(((uint64_t)n * (m + 1)) / avail);
+      if (next < cut) next = cut;
+      while (next < n && next > 0 && v[next] == v[next - 1]) ++next;
+      a.seg_begin[id0 + m] = begin + cut;
+      a.seg_end[id0 + m] = begin + next;
+      a.seg_hif[id0 + m] = 0;  // bounds given as keys
+      a.seg_lokey[id0 + m] = next > cut ? v[cut] : 0;
+      a.seg_span[id0 + m] = next > cut ? v[next - 1] - v[cut] + 1 : 0;
+      cut = next;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void uniq_count(UniqArgs u) {
@@ -801,7 +1091,16 @@ struct MinPlan {
   // workspace offsets
   size_t o_nchunks, o_chunk_base, o_windows, o_wbase, o_counter, o_exit_f, o_exit_c, o_resolved, o_keys,
       o_sorted, o_seg_begin, o_seg_end, o_big_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_scan_state, o_tmp;
+  // one sequence of moderate length: bucketed sort (bucket_plan)
+  bool buckets;
+  uint32_t nseg, fine_shift;
+  size_t o_bucket_zero, bucket_zero_bytes;  // one zeroed block: histogram, bucket tables, scan state + ticket
+  size_t o_hist, o_bseg_begin, o_bseg_end, o_bseg_lof, o_bseg_hif, o_bseg_lokey, o_bseg_span, o_bscan;
 };
+
+// longest single sequence (in windows) that takes the bucketed sort: beyond it a device-wide radix sort is
+// bound by bandwidth, not by its number of launches, and the fine bins would hold too many keys each
+constexpr uint64_t kBucketMaxWindows = 32u << 20;
 
 uint32_t bits_for(uint64_t v) {
   uint32_t b = 0;
@@ -877,6 +1176,22 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_tile_count = take(mt * 4);
   pl->o_tile_off = take(mt * 8);
   pl->o_scan_state = take(((size_t)n + 1) * 8);  // look-back scan of the fused sort/output kernel + its ticket
+  pl->buckets = n == 1 && variant == SA_MIN_BINARY && pl->capacity <= kBucketMaxWindows;
+  pl->nseg = (uint32_t)(pl->capacity / kBucketKeys + 2);
+  pl->fine_shift = pl->end_bit > kFineBits ? pl->end_bit - kFineBits : 0;
+  if (pl->buckets) {
+    const size_t ns = pl->nseg;
+    pl->o_bucket_zero = o;
+    pl->o_hist = take((size_t)kFine * 4);
+    pl->o_bseg_begin = take(ns * 4);
+    pl->o_bseg_end = take(ns * 4);
+    pl->o_bseg_lof = take(ns * 4);
+    pl->o_bseg_hif = take(ns * 4);
+    pl->o_bseg_lokey = take(ns * 8);
+    pl->o_bseg_span = take(ns * 8);
+    pl->o_bscan = take((ns + 2) * 8);  // scan state, ticket, buckets in use
+    pl->bucket_zero_bytes = o - pl->o_bucket_zero;
+  }
   pl->o_tmp = take(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), pl->sort_tmp));
   pl->total_bytes = o;
   return SA_OK;
@@ -963,19 +1278,25 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.keys = keys;
   a.status = b->d_status;
   a.other = other;
-  if (b->d_status) SA_HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), stream));
-  SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 3) * 4, stream));
-  SA_HIP_TRY(hipMemsetAsync(tile_count, 0, ((size_t)pl.max_tiles + 1) * 4, stream));
-
   auto blocks = [](uint64_t items) { return dim3((unsigned)((items + kThreads - 1) / kThreads)); };
-  hipLaunchKernelGGL(min_seq_plan, blocks(b->n + 1), dim3(kThreads), 0, stream, b->d_off, b->n, b->k,
-                     b->w, pl.chunk, nchunks, windows);
-  size_t t = pl.scan32_tmp;
-  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, nchunks, chunk_base, 0u, (size_t)b->n + 1,
-                                     rocprim::plus<uint32_t>(), stream));
-  t = pl.scan32_tmp;
-  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, windows, wbase, 0u, (size_t)b->n + 1,
-                                     rocprim::plus<uint32_t>(), stream));
+  size_t t = 0;
+  if (pl.buckets) {  // one sequence: the bookkeeping in one launch, the bucket tables cleared alongside
+    SA_HIP_TRY(hipMemsetAsync(ws + pl.o_bucket_zero, 0, pl.bucket_zero_bytes, stream));
+    hipLaunchKernelGGL(min_plan_single, dim3(1), dim3(64), 0, stream, b->d_off, b->k, b->w, pl.chunk, nchunks,
+                       chunk_base, windows, wbase, counter, b->d_status);
+  } else {
+    if (b->d_status) SA_HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), stream));
+    SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 3) * 4, stream));
+    SA_HIP_TRY(hipMemsetAsync(tile_count, 0, ((size_t)pl.max_tiles + 1) * 4, stream));
+    hipLaunchKernelGGL(min_seq_plan, blocks(b->n + 1), dim3(kThreads), 0, stream, b->d_off, b->n, b->k,
+                       b->w, pl.chunk, nchunks, windows);
+    t = pl.scan32_tmp;
+    SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, nchunks, chunk_base, 0u, (size_t)b->n + 1,
+                                       rocprim::plus<uint32_t>(), stream));
+    t = pl.scan32_tmp;
+    SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, windows, wbase, 0u, (size_t)b->n + 1,
+                                       rocprim::plus<uint32_t>(), stream));
+  }
   if (b->variant == SA_MIN_BINARY) {
     const bool long_k = b->k > 16;  // a third history word
     auto* run = long_k     ? min_run<Machine<0, true>>
@@ -995,6 +1316,52 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     hipLaunchKernelGGL(fix_x, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
   } else {
     hipLaunchKernelGGL(dec_run, blocks(b->n), dim3(kThreads), 0, stream, a);
+  }
+  if (pl.buckets) {
+    // one sequence: value-ordered buckets of about a thousand keys, sorted and written by sort_emit_small
+    BucketArgs ba{};
+    ba.keys = keys;
+    ba.grouped = sorted;
+    ba.count = counter;
+    ba.fine_shift = pl.fine_shift;
+    ba.hist = (uint32_t*)(ws + pl.o_hist);
+    ba.nseg = pl.nseg;
+    ba.seg_begin = (uint32_t*)(ws + pl.o_bseg_begin);
+    ba.seg_end = (uint32_t*)(ws + pl.o_bseg_end);
+    ba.seg_lof = (uint32_t*)(ws + pl.o_bseg_lof);
+    ba.seg_hif = (uint32_t*)(ws + pl.o_bseg_hif);
+    ba.seg_lokey = (uint64_t*)(ws + pl.o_bseg_lokey);
+    ba.seg_span = (uint64_t*)(ws + pl.o_bseg_span);
+    ba.nseg_used = (uint32_t*)((uint64_t*)(ws + pl.o_bscan) + pl.nseg + 1);
+    const dim3 sweep((unsigned)std::min<uint64_t>((pl.capacity + 4 * kThreads - 1) / (4 * kThreads), 2048));
+    hipLaunchKernelGGL(bucket_hist, sweep, dim3(kThreads), 0, stream, ba);
+    hipLaunchKernelGGL(bucket_plan, dim3(1), dim3(kThreads), 0, stream, ba);
+    hipLaunchKernelGGL(bucket_scatter, sweep, dim3(kThreads), 0, stream, ba);
+    hipLaunchKernelGGL(bucket_split, dim3(pl.nseg), dim3(kThreads), 0, stream, ba);
+    EmitArgs ea{};
+    ea.keys = sorted;
+    ea.seg_begin = ba.seg_begin;
+    ea.seg_end = ba.seg_end;
+    ea.n = pl.nseg;
+    ea.key_shift = pl.key_shift;
+    ea.value_bits = pl.end_bit - pl.key_shift;
+    ea.scan_state = (uint64_t*)(ws + pl.o_bscan);
+    ea.ticket = (uint32_t*)(ea.scan_state + pl.nseg);
+    ea.n_big = n_big;
+    ea.out_capacity = b->out_capacity;
+    ea.out = b->d_out;
+    ea.out_off = b->d_out_off;
+    ea.status = b->d_status;
+    ea.buckets = 1;
+    ea.nseg_used = ba.nseg_used;
+    ea.fine_shift = pl.fine_shift;
+    ea.seg_lof = ba.seg_lof;
+    ea.seg_hif = ba.seg_hif;
+    ea.seg_lokey = ba.seg_lokey;
+    ea.seg_span = ba.seg_span;
+    hipLaunchKernelGGL(sort_emit_small, dim3(pl.nseg), dim3(kThreads), 0, stream, ea);
+    SA_HIP_TRY(hipGetLastError());
+    return SA_OK;
   }
   hipLaunchKernelGGL(min_segments, blocks(b->n + 1), dim3(kThreads), 0, stream, wbase, counter, b->n,
                      seg_begin, seg_end, big_end, tiles, n_big);

@@ -205,3 +205,38 @@ def test_reads_with_many_repeated_keys_vs_oracle(oracle):
                 assert np.array_equal(r, oracle.minimize_binary_array(s, k, w)), (k, w, len(s))
     finally:
         capi.set_option("min_chunk", 0)
+
+
+def test_single_sequence_bucketed_sort_vs_oracle(oracle):
+    """A call on ONE sequence cuts its keys into value-ordered buckets of about a thousand keys and sorts those
+    inside LDS.  Buckets are runs of whole fine bins (the top 16 bits of a key), so a value that repeats at
+    thousands of positions makes a bucket larger than the LDS sort takes: it is sorted in global memory and
+    handed out in slices.  Random sequence, tandem repeats of several periods (a handful of values at tens of
+    thousands of positions each), a repeat inside random sequence, tiny sequences, small k (fewer key bits than
+    fine-bin bits), k above 16, bytes other than bases (the second run of the exact machine), tiny chunks
+    (repeated keys at every chunk boundary)."""
+    from sequencealigner_amd import capi, minimize, synth
+    g = bytes(synth.genome(300_000, seed=601))
+    cases = [
+        (g, 15, 5),
+        (b"ACGTTGC" * 60_000, 15, 5),
+        (b"ACGTTGCAAC" * 30_000 + g[:50_000] + b"AC" * 40_000 + b"T" * 30_000, 15, 5),
+        (g[:120_000] + g[1000:31_000] * 6 + g[120_000:200_000], 15, 5),
+        (g[:19], 15, 5),
+        (g[:700], 15, 5),
+        (g, 5, 3),
+        (g, 2, 1),
+        (b"ACGTTGC" * 60_000, 4, 5),
+        (g, 21, 11),
+        (g[:100_000] + b"N" * 300 + g[100_000:150_000] + b"n" + g[150_000:], 15, 5),
+        (g, 16, 17),
+    ]
+    for seq, k, w in cases:
+        got = minimize.minimize_binary(seq, k, w)
+        assert np.array_equal(got, oracle.minimize_binary_array(seq, k, w)), (len(seq), k, w)
+    capi.set_option("min_chunk", 8)
+    try:
+        got = minimize.minimize_binary(g[:90_000], 15, 5)
+        assert np.array_equal(got, oracle.minimize_binary_array(g[:90_000], 15, 5))
+    finally:
+        capi.set_option("min_chunk", 0)
