@@ -78,11 +78,13 @@ struct Pk16Args {
   // Packed sequences, written by pack_lane_pk16 in one of two forms (see AlphabetInfo::small):
   //  symbols: qpk[unit][max_q][64] dwords, tpk[unit][t_pad][64] dwords - the byte of pair A in the low
   //           half, of pair B in the high half (pads: kQueryPad / kTargetPad);
-  //  tables:  qpk[unit][max_q][64] dwords - the symbol CODES (0..3) of the two pairs in the halves, 0xFFFF
-  //           beyond the query; per column the fill expands each code into a 4-byte table whose byte L is
-  //           (sub(L, q) - gap) << SH (all 0 beyond the query);
-  //           tpk[unit][t_pad][64] dwords - v_perm selectors {code A, 0x0C, 4 + code B, 0x0C} that pick
-  //           the pair's entry out of {table B, table A} (0x0C = constant 0, also used beyond the target).
+  //  tables:  one BYTE per position, four positions per dword: qpk[unit][max_q / 4][64], tpk[unit][t_pad / 4][64]
+  //           (a quarter of the symbols form's bytes to write, and to read once per strip).
+  //           Query byte: the symbol CODES (0..3) of pair A / pair B in the low / high nibble, 0xF beyond the
+  //           query; per column the fill expands each code into a 4-byte table whose byte L is
+  //           (sub(L, q) - gap) << SH (all 0 beyond the query).
+  //           Target byte: the nibbles of the v_perm selector {code A, 0x0C, 4 + code B, 0x0C} that picks the
+  //           pair's entry out of {table B, table A} (0xC = constant 0, also used beyond the target).
   const uint32_t* qpk;
   const uint32_t* tpk;
   uint32_t t_pad;       // nstrips * K
@@ -187,8 +189,20 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
   uint32_t Tk[KS], Hc[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    Tk[k] = tpk[(uint64_t)(i0 + k) * 64];
+    if (!PERM) Tk[k] = tpk[(uint64_t)(i0 + k) * 64];
     Hc[k] = SG(border_col0<MODE>((int)(i0 + 1 + k), gap) + gap);  // column 0: S(H[i][0] + gap)
+  }
+  if (PERM) {  // four rows per dword (i0 is a multiple of 16): selector nibbles -> selectors
+#pragma unroll
+    for (int k4 = 0; k4 < KS; k4 += 4) {
+      const uint32_t w = tpk[(uint64_t)(i0 / 4 + k4 / 4) * 64];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (k4 + x >= KS) break;
+        const uint32_t b = (w >> (8 * x)) & 0xFFu;
+        Tk[k4 + x] = (b & 0xFu) | ((b >> 4) << 16) | 0x0C000C00u;
+      }
+    }
   }
   // S(H[i0][0] + gap): base of the diagonal of row i0+1 at column 1
   uint32_t top_prev = SG(((i0 == 0) ? 0 : border_col0<MODE>((int)i0, gap)) + gap);
@@ -196,7 +210,8 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
   uint32_t best = st.best;
   const uint32_t tab_base = x.entry_mismatch * 0x01010101u;
   const uint32_t tab_delta = x.entry_match - x.entry_mismatch;
-  uint32_t qq = qpk[0];
+  uint32_t qq = qpk[0];  // symbols: column 1's symbols; tables: the bytes of columns 1..4
+  uint32_t qq_next = 0;
   uint32_t top_next = 0;
   if (s != 0)
     top_next = __hip_atomic_load(&brow[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -204,11 +219,16 @@ __device__ __forceinline__ void lane_pk16_strip(const AlignArgs& a, const Pk16Ar
     // symbols form: x = the two pairs' query symbols; tables form: (x, y) = the two pairs' score tables
     uint2 qcur = make_uint2(qq, 0);
     if (PERM) {
-      const uint32_t ca = qq & 0xFFFFu, cb = qq >> 16;
+      const uint32_t x = (r - 1) & 3u;  // the column's byte of the group's dword
+      if (x == 0 && r + 4 <= maxQ) qq_next = qpk[(uint64_t)((r - 1) / 4 + 1) * 64];  // the next four columns
+      const uint32_t b = (qq >> (8 * x)) & 0xFFu;
+      const uint32_t ca = b & 0xFu, cb = b >> 4;
       qcur.x = ca > 3 ? 0u : tab_base + (tab_delta << (8 * ca));
       qcur.y = cb > 3 ? 0u : tab_base + (tab_delta << (8 * cb));
+      if (x == 3) qq = qq_next;
+    } else if (r < maxQ) {
+      qq = qpk[(uint64_t)r * 64];  // prefetch the next column
     }
-    if (r < maxQ) qq = qpk[(uint64_t)r * 64];  // prefetch the next column
     // The boundary row of the strip above is fetched one column ahead as well.  (Read past this CU's
     // L1: the same addresses were read and then overwritten while the previous strip ran.)
     const uint32_t top = (s == 0) ? SG(border_row0<MODE>((int)r, gap) + gap) : top_next;
@@ -642,31 +662,46 @@ __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
   }
   const uint32_t pad = is_query ? kQueryPad : kTargetPad;
   uint32_t unseen = 0;
-  // the word index is unrolled (registers), the byte index is a loop: the compact form keeps more
-  // wavefronts resident, which matters more here than the instruction count
+  if (!tables) {
+    // the word index is unrolled (registers), the byte index is a loop: the compact form keeps more
+    // wavefronts resident, which matters more here than the instruction count
 #pragma unroll
-  for (uint32_t j = 0; j < 8; ++j) {
-    uint64_t ra = wa[j], rb = wb[j];
+    for (uint32_t j = 0; j < 8; ++j) {
+      uint64_t ra = wa[j], rb = wb[j];
 #pragma unroll 1
-    for (uint32_t c = 8 * j; c < 8 * j + 8; ++c, ra >>= 8, rb >>= 8) {
-      const uint32_t pos = t0 + c;
-      if (pos >= len_cap) break;
-      const bool inA = pos < lenA, inB = pos < lenB;
-      const uint32_t ba = (uint32_t)ra & 0xFFu, bb = (uint32_t)rb & 0xFFu;
-      uint32_t v;
-      if (!tables) {
-        v = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
-      } else {
-        const uint32_t ca = inA ? (uint32_t)code[ba] : 0u, cb = inB ? (uint32_t)code[bb] : 0u;
-        unseen |= ca | cb;
-        if (is_query) {
-          v = (inA ? ca : 0xFFFFu) | ((inB ? cb : 0xFFFFu) << 16);
-        } else {
-          const uint32_t sa = inA ? ca : 0x0Cu, sb = inB ? 4u + cb : 0x0Cu;
-          v = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
-        }
+      for (uint32_t c = 8 * j; c < 8 * j + 8; ++c, ra >>= 8, rb >>= 8) {
+        const uint32_t pos = t0 + c;
+        if (pos >= len_cap) break;
+        const bool inA = pos < lenA, inB = pos < lenB;
+        const uint32_t ba = (uint32_t)ra & 0xFFu, bb = (uint32_t)rb & 0xFFu;
+        const uint32_t v = (inA ? ba : pad) | ((inB ? bb : pad) << 16);
+        __builtin_nontemporal_store(v, &out[(uint64_t)c * 64]);  // read once, by the fill, much later
       }
-      __builtin_nontemporal_store(v, &out[(uint64_t)c * 64]);  // read once, by the fill, much later
+    }
+  } else {
+    // one byte per position (nibbles: pair A, pair B), four positions per dword
+    uint32_t* out4 = (is_query ? a.qpk : a.tpk) + ((uint64_t)unit * len_cap + t0 / 4) * 64 + lane;
+    const uint32_t padn = is_query ? 0xFu : 0xCu, addb = is_query ? 0u : 4u;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+      uint64_t ra = wa[j], rb = wb[j];
+#pragma unroll 1
+      for (uint32_t g = 0; g < 2; ++g) {
+        const uint32_t c0 = 8 * j + 4 * g;
+        if (t0 + c0 >= len_cap) break;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 4; ++x, ra >>= 8, rb >>= 8) {
+          const uint32_t pos = t0 + c0 + x;
+          const bool inA = pos < lenA, inB = pos < lenB;
+          const uint32_t ca = inA ? (uint32_t)code[(uint32_t)ra & 0xFFu] : 0u;
+          const uint32_t cb = inB ? (uint32_t)code[(uint32_t)rb & 0xFFu] : 0u;
+          unseen |= ca | cb;
+          const uint32_t na = inA ? (ca & 3u) : padn, nb = inB ? addb + (cb & 3u) : padn;
+          v |= (na | (nb << 4)) << (8 * x);
+        }
+        __builtin_nontemporal_store(v, &out4[(uint64_t)(c0 / 4) * 64]);  // read once, by the fill, much later
+      }
     }
   }
   if (unseen & kUnseen) a.alpha->violated = 1;
