@@ -224,6 +224,9 @@ size_t sa_minimize_workspace_bytes(uint32_t n, uint64_t total_len, uint32_t max_
                                    uint32_t w, int variant);
 uint64_t sa_minimize_out_capacity(uint32_t n, uint64_t total_len, uint32_t k, uint32_t w);
 
+/* Only enqueues work on `stream` when the batch holds reads (every sequence at most 2048 windows long) or
+ * ONE sequence of up to 32 M windows; other batches (several long sequences) synchronise the stream once
+ * inside the segmented sort they use. */
 int sa_minimize_batch_device(int device, void* stream, const sa_minimize_batch* batch,
                              void* d_workspace, size_t workspace_bytes);
 

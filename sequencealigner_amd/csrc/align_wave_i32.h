@@ -112,6 +112,17 @@ struct WaveCoop {
 
 constexpr uint32_t kSpinLimit = 1u << 24;
 
+// f(integral_constant<0>) ... f(integral_constant<N-1>): indices that are constants from the start, so that a
+// small array indexed with them stays in registers (a loop the optimiser unrolls later left the traceback's
+// prefetched tile in scratch memory, and with it a wait for the prefetch at the place it was issued)
+template <uint32_t N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<uint32_t, N - 1>{});
+  }
+}
+
 __device__ __forceinline__ int dpp_from_lane_below(int v) {
   // wave_shr:1 - lane L receives lane L-1's value, lane 0 keeps `old` (0)
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
@@ -487,7 +498,10 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   // The tile holds steps [tile_lo, tile_lo + TS) x lanes [tile_lb, tile_lb + TW) of strip tile_s (steps
   // counted from U0): the path moves towards smaller steps and lanes, about one lane per C diagonal moves.
   uint32_t tile_s = ~0u, tile_lo = 0, tile_lb = 0;
-  uint4 pre[kVecPerLane];              // the predicted next tile, on its way in
+  // (a native vector type: copies of the uint4 struct are memcpy calls between address spaces, which kept this
+  // array in scratch memory and made the prefetch wait for its loads at once)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 pre[kVecPerLane];              // the predicted next tile, on its way in
   uint32_t pre_s = ~0u, pre_lo = 0, pre_lb = 0;
   uint32_t ts_base = 0;                // ts[x] = t[ts_base + x]
   // lane base of a tile whose top lanes include L (vector-aligned, inside the 64 lanes)
@@ -495,9 +509,9 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
     const uint32_t lb = top + WPV >= TW ? ((top + WPV - TW) / WPV) * WPV : 0u;
     return lb > 64 - TW ? 64 - TW : lb;
   };
-  auto tile_vec = [&](uint32_t s, uint32_t lo, uint32_t lb, uint32_t x) -> const uint4* {
+  auto tile_vec = [&](uint32_t s, uint32_t lo, uint32_t lb, uint32_t x) -> const u32x4* {
     const uint32_t v = x * 64 + lane, row = v / VPR, colv = v % VPR;
-    return reinterpret_cast<const uint4*>(dirs + ((uint64_t)s * nrows + lo / SPW + row) * 64 + lb) + colv;
+    return reinterpret_cast<const u32x4*>(dirs + ((uint64_t)s * nrows + lo / SPW + row) * 64 + lb) + colv;
   };
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
@@ -515,15 +529,13 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       if (s != tile_s || (st & ~(TS - 1)) != tile_lo || L < tile_lb || L >= tile_lb + TW) {
         __syncthreads();
         const uint32_t lo = st & ~(TS - 1);
-        uint4* dst = reinterpret_cast<uint4*>(tile);
+        u32x4* dst = reinterpret_cast<u32x4*>(tile);
         if (s == pre_s && lo == pre_lo && L >= pre_lb && L < pre_lb + TW) {
           tile_lb = pre_lb;
-#pragma unroll
-          for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = pre[x];
+          static_for<kVecPerLane>([&](auto x) { dst[x * 64 + lane] = pre[x]; });
         } else {
           tile_lb = lane_base(L);
-#pragma unroll
-          for (uint32_t x = 0; x < kVecPerLane; ++x) dst[x * 64 + lane] = *tile_vec(s, lo, tile_lb, x);
+          static_for<kVecPerLane>([&](auto x) { dst[x * 64 + lane] = *tile_vec(s, lo, tile_lb, x); });
         }
         if (s != tile_s) {
 #pragma unroll
@@ -559,10 +571,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         } else {
           pre_s = ~0u;
         }
-        if (pre_s != ~0u) {
-#pragma unroll
-          for (uint32_t x = 0; x < kVecPerLane; ++x) pre[x] = *tile_vec(pre_s, pre_lo, pre_lb, x);
-        }
+        if (pre_s != ~0u) static_for<kVecPerLane>([&](auto x) { pre[x] = *tile_vec(pre_s, pre_lo, pre_lb, x); });
         __syncthreads();
       }
       // Lane x looks at the cell x steps further along the diagonal, (i - x, r - x): the path follows
