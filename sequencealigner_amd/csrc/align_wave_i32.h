@@ -495,6 +495,29 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
+  // Finished runs wait in `runbuf`, one per lane, and leave with one store per iteration: the walk is a chain
+  // of scalar instructions on one wavefront, a store per run (address, lane mask) was a good part of it.
+  uint32_t runbuf = 0, nbuf = 0;
+  auto flush_runs = [&]() __attribute__((always_inline)) {
+    if (slot_end && lane < nbuf) slot_end[-(int64_t)(nruns + 1 + lane)] = runbuf;
+    nruns += nbuf;
+    nbuf = 0;
+  };
+  auto push_run = [&](uint32_t run) __attribute__((always_inline)) {
+    if (nbuf == 64) flush_runs();
+    runbuf = lane == nbuf ? run : runbuf;
+    ++nbuf;
+  };
+  // a run of `len` moves of kind op, in path order: joins the run in progress or closes it
+  auto emit = [&](uint32_t op, uint32_t len) __attribute__((always_inline)) {
+    if (op == cur_op) {
+      cur_len += len;
+    } else {
+      if (cur_len) push_run((cur_len << 2) | cur_op);
+      cur_op = op;
+      cur_len = len;
+    }
+  };
   // The tile holds steps [tile_lo, tile_lo + TS) x lanes [tile_lb, tile_lb + TW) of strip tile_s (steps
   // counted from U0): the path moves towards smaller steps and lanes, about one lane per C diagonal moves.
   uint32_t tile_s = ~0u, tile_lo = 0, tile_lb = 0;
@@ -602,24 +625,25 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         }
         i -= n;
         r -= n;
-        for (uint32_t done = 0; done < n;) {  // maximal runs of equal bits, in path order
-          const uint64_t rest = eqs >> done;
-          const bool m = rest & 1ull;
-          const uint64_t flip = m ? ~rest : rest;
-          uint32_t len = flip ? (uint32_t)__builtin_ctzll(flip) : 64u;
-          if (len > n - done) len = n - done;
-          const uint32_t op = m ? SA_OP_M : SA_OP_X;
-          if (op == cur_op) {
-            cur_len += len;
-          } else {
-            if (cur_len) {
-              ++nruns;
-              if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
-            }
-            cur_op = op;
-            cur_len = len;
+        {  // maximal runs of equal bits, in path order: the first may continue the run in progress, the others
+           // alternate between M and X and start where neighbouring bits differ
+          const uint32_t first = (eqs & 1ull) ? SA_OP_M : SA_OP_X;
+          if (first != cur_op) {
+            if (cur_len) push_run((cur_len << 2) | cur_op);
+            cur_op = first;
+            cur_len = 0;
           }
-          done += len;
+          uint64_t turns = (eqs ^ (eqs >> 1)) & (in_run >> 1);  // bit x: cell x + 1 differs from cell x
+          uint32_t prev = 0;
+          while (turns) {
+            const uint32_t at = (uint32_t)__builtin_ctzll(turns) + 1;
+            turns &= turns - 1;
+            push_run(((cur_len + at - prev) << 2) | cur_op);
+            cur_op ^= SA_OP_M ^ SA_OP_X;
+            cur_len = 0;
+            prev = at;
+          }
+          cur_len += n - prev;
         }
         // Lane n looked at the cell the run stopped at: when that is a gap move (and, for Local, not a cell
         // with score 0, which is None whatever its flags say), take it in the same iteration - single gaps
@@ -632,17 +656,9 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
           else
             i -= 1;
           if (MODE == SA_LOCAL) remaining -= a.gap;
-          if (op == cur_op) {
-            cur_len += 1;
-          } else {
-            if (cur_len) {
-              ++nruns;
-              if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
-            }
-            cur_op = op;
-            cur_len = 1;
-          }
+          emit(op, 1);
         }
+        flush_runs();
         continue;
       }
       d = __builtin_amdgcn_readfirstlane(dx);  // lane 0 holds the current cell
@@ -680,22 +696,12 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       i -= len;
     }
     if (MODE == SA_LOCAL) remaining -= a.gap * (int)len;
-    if (op == cur_op) {
-      cur_len += len;
-    } else {
-      if (cur_len) {
-        ++nruns;
-        if (slot_end && lane == 0) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
-      }
-      cur_op = op;
-      cur_len = len;
-    }
+    emit(op, len);
+    flush_runs();
   }
+  if (cur_len) push_run((cur_len << 2) | cur_op);
+  flush_runs();
   if (lane != 0) return;
-  if (cur_len) {
-    ++nruns;
-    if (slot_end) slot_end[-(int64_t)nruns] = (cur_len << 2) | cur_op;
-  }
   if (a.cigar_nruns) a.cigar_nruns[p] = nruns;
   if (a.target_begin) {
     if (MODE == SA_LOCAL)
