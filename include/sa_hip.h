@@ -65,10 +65,12 @@ const char* sa_device_arch(int device);
  *   "force_i32"     (SA_FORCE_I32)     1: never use the packed 16-bit kernels
  *   "force_family"  (SA_FORCE_FAMILY=lane|wave)  0 automatic, 1 lane kernels, 2 wavefront kernels
  *   "force_coop"    (SA_FORCE_COOP)    -1 automatic, 0 / 1: cooperative wavefront kernel off / on where possible
- *   "no_tables"     (SA_NO_TABLES)     1: packed lane kernel without score tables
+ *   "no_tables"     (SA_NO_TABLES)     1: no kernel looks substitution scores up in tables
  *   "coop_c"        (SA_COOP_C)        columns per lane of the cooperative kernel, 0 automatic
  *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64
  *   "min_chunk"     (SA_MIN_CHUNK)     windows per minimizer chunk, 0 automatic
+ *   "no_buckets"    (SA_NO_BUCKETS)    1: a single sequence is sorted by the device-wide radix sort, as sequences
+ *                                      beyond 32 M windows always are
  *   "fake_devices"  (SA_FAKE_DEVICES)  the host batch calls deal their units to this many shards, all run on
  *                                      GPU 0 at the same time (the multi-GPU path on a one-GPU machine)
  * A call that is planning a batch while an option changes may see either value; set options between calls. */

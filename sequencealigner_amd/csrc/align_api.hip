@@ -45,6 +45,7 @@ Options& options() {
     x->coop_c = num("SA_COOP_C", 0);
     x->pk16_k = num("SA_PK16_K", 48);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
+    x->no_buckets = num("SA_NO_BUCKETS", 0);
     x->fake_devices = num("SA_FAKE_DEVICES", 0);
     return x;
   }();
@@ -499,7 +500,8 @@ int sa_set_option(const char* name, long value) {
     std::atomic<long>* slot;
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"pk16_k", &o.pk16_k},
-               {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices}};
+               {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
+               {"no_buckets", &o.no_buckets}};
   for (auto& e : table)
     if (!strcmp(name, e.name)) {
       *e.slot = value;

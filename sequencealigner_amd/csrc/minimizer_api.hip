@@ -590,8 +590,9 @@ struct EmitArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
-  // one buffer, two uses: [0, 4096) grouped keys + [4096, 6144) bins while sorting, then the staged triples
-  __shared__ __attribute__((aligned(16))) uint32_t buf[3 * kSmallMax];
+  // one buffer, two uses: [0, 4096) grouped keys + [4096, 5120) bin counters (16 bits each, two per dword)
+  // while sorting, then the staged (value, position << 1 | strand) pairs.  20 KB: eight blocks per CU.
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2 * kSmallMax + kBins / 2];
   __shared__ uint32_t lds[kThreads / 64];
   __shared__ uint32_t dup_rank[64];  // ranks of keys that repeat their predecessor (few, if any)
   __shared__ uint32_t s_seq, s_ndup;
@@ -599,9 +600,13 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   __shared__ uint64_t lb_sum[kThreads / 64];   // look-back: per wave, the counts it may add
   __shared__ uint32_t lb_flag[kThreads / 64];  //   bit 0: usable, bit 1: ends at a prefix
   uint64_t* grouped = reinterpret_cast<uint64_t*>(buf);
-  uint32_t* bins = buf + 2 * kSmallMax;
+  uint32_t* bins2 = buf + 2 * kSmallMax;  // bin b: half b & 1 of bins2[b >> 1] (counts and positions <= 2048)
   uint32_t* stage = buf;
-  static_assert(kBins == kSmallMax, "LDS layout");
+  static_assert(kBins == kSmallMax && kSmallMax <= 0x8000, "LDS layout, 16-bit bin counters");
+  auto bin_get = [&](uint32_t b) -> uint32_t { return (bins2[b >> 1] >> (16 * (b & 1))) & 0xFFFFu; };
+  auto bin_inc = [&](uint32_t b) -> uint32_t {  // value before the increment
+    return (atomicAdd(&bins2[b >> 1], 1u << (16 * (b & 1))) >> (16 * (b & 1))) & 0xFFFFu;
+  };
   const uint32_t tid = threadIdx.x;
   if (!a.buckets && *a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
   if (tid == 0) {
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
     return b < kBins ? (uint32_t)b : kBins - 1;
   };
 #pragma unroll
-  for (uint32_t e = 0; e < kBinsPer; ++e) bins[tid + e * kThreads] = 0;
+  for (uint32_t e = 0; e < kBinsPer / 2; ++e) bins2[tid + e * kThreads] = 0;
   __syncthreads();
   uint64_t mine[kPer];
   uint32_t bin[kPer];
@@ -650,28 +655,32 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
     if (i < count) {
       mine[e] = a.keys[begin + i];
       bin[e] = bin_of(mine[e]);
-      atomicAdd(&bins[bin[e]], 1u);
+      bin_inc(bin[e]);
     }
   }
   __syncthreads();
+  // exclusive scan of the bin counts: thread t owns bins t * kBinsPer .. (kBinsPer / 2 dwords)
   uint32_t local[kBinsPer], sum = 0;
 #pragma unroll
-  for (uint32_t e = 0; e < kBinsPer; ++e) {
-    local[e] = bins[tid * kBinsPer + e];
-    sum += local[e];
+  for (uint32_t e = 0; e < kBinsPer / 2; ++e) {
+    const uint32_t w = bins2[tid * (kBinsPer / 2) + e];
+    local[2 * e] = w & 0xFFFFu;
+    local[2 * e + 1] = w >> 16;
+    sum += local[2 * e] + local[2 * e + 1];
   }
   uint32_t excl;
   block_sum(sum, lds, &excl);
 #pragma unroll
-  for (uint32_t e = 0; e < kBinsPer; ++e) {
-    bins[tid * kBinsPer + e] = excl;
-    excl += local[e];
+  for (uint32_t e = 0; e < kBinsPer / 2; ++e) {
+    const uint32_t lo16 = excl, hi16 = excl + local[2 * e];
+    bins2[tid * (kBinsPer / 2) + e] = lo16 | (hi16 << 16);
+    excl = hi16 + local[2 * e + 1];
   }
   __syncthreads();
 #pragma unroll
   for (uint32_t e = 0; e < kPer; ++e) {
     const uint32_t i = tid + e * kThreads;
-    if (i < count) grouped[atomicAdd(&bins[bin[e]], 1u)] = mine[e];
+    if (i < count) grouped[bin_inc(bin[e])] = mine[e];
   }
   __syncthreads();
   // bins[b] is now the end of bin b: rank every key among the keys of its bin; a key that has an equal key
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
       const uint64_t key = grouped[p];
       mine[e] = key;
       const uint32_t b = bin_of(key);
-      const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
+      const uint32_t lo = b ? bin_get(b - 1) : 0, hi = bin_get(b);
       uint32_t r = lo;
       bool dup = false;
       for (uint32_t m = lo; m < hi; ++m) {
@@ -823,7 +832,7 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
       upos[e] = rank[e] - d;
     }
   } else {  // many repeats (never seen on real sequences): mark the duplicates' ranks and count below each rank
-    uint32_t* is_dup = bins;
+    uint32_t* is_dup = buf;  // (the grouped keys are no longer needed, the staging area not yet written)
 #pragma unroll
     for (uint32_t e = 0; e < kBinsPer; ++e) is_dup[tid + e * kThreads] = 0;
     __syncthreads();
@@ -845,16 +854,19 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   for (uint32_t e = 0; e < kPer; ++e) {
     if (rank[e] & 0x80000000u) continue;  // beyond the keys, or a duplicate
     const uint32_t u = upos[e];
-    stage[3 * u] = (uint32_t)(mine[e] >> a.key_shift);
-    stage[3 * u + 1] = (uint32_t)((mine[e] & low) >> 1);
-    stage[3 * u + 2] = (uint32_t)(mine[e] & 1);
+    stage[2 * u] = (uint32_t)(mine[e] >> a.key_shift);
+    stage[2 * u + 1] = (uint32_t)(mine[e] & low);  // position << 1 | strand (sequences here are far below 2^31)
   }
   __syncthreads();
   const uint64_t first_out = s_excl;
   const uint64_t room = first_out < a.out_capacity ? a.out_capacity - first_out : 0;
   const uint32_t dwords = 3 * (uint32_t)(uniq < room ? uniq : room);
   uint32_t* dst = a.out + 3 * first_out;
-  for (uint32_t x = tid; x < dwords; x += kThreads) dst[x] = stage[x];
+  for (uint32_t x = tid; x < dwords; x += kThreads) {  // dword x of the run of (value, position, strand) triples
+    const uint32_t u = x / 3, part = x - 3 * u;
+    const uint32_t ps = stage[2 * u + 1];
+    dst[x] = part == 0 ? stage[2 * u] : part == 1 ? ps >> 1 : ps & 1u;
+  }
 }
 
 // ---- one long sequence: its keys are cut into value-ordered buckets of about kBucketKeys keys, which
@@ -1176,7 +1188,7 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_tile_count = take(mt * 4);
   pl->o_tile_off = take(mt * 8);
   pl->o_scan_state = take(((size_t)n + 1) * 8);  // look-back scan of the fused sort/output kernel + its ticket
-  pl->buckets = n == 1 && variant == SA_MIN_BINARY && pl->capacity <= kBucketMaxWindows;
+  pl->buckets = n == 1 && variant == SA_MIN_BINARY && pl->capacity <= kBucketMaxWindows && !options().no_buckets;
   pl->nseg = (uint32_t)(pl->capacity / kBucketKeys + 2);
   pl->fine_shift = pl->end_bit > kFineBits ? pl->end_bit - kFineBits : 0;
   if (pl->buckets) {

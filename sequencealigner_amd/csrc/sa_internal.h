@@ -43,6 +43,7 @@ struct Options {
   std::atomic<long> coop_c{0};        // SA_COOP_C: columns per lane of the cooperative kernel (0 automatic)
   std::atomic<long> pk16_k{48};       // SA_PK16_K: rows per strip of the packed lane kernel (32, 48, 64)
   std::atomic<long> min_chunk{0};     // SA_MIN_CHUNK: windows per minimizer chunk (0 automatic, 8..4096)
+  std::atomic<long> no_buckets{0};    // SA_NO_BUCKETS: single sequences take the device-wide radix sort
   std::atomic<long> fake_devices{0};  // SA_FAKE_DEVICES: the host batch calls deal to this many shards, all of
                                       // them on GPU 0 (exercises the multi-GPU path on one GPU)
 };

@@ -240,3 +240,16 @@ def test_single_sequence_bucketed_sort_vs_oracle(oracle):
         assert np.array_equal(got, oracle.minimize_binary_array(g[:90_000], 15, 5))
     finally:
         capi.set_option("min_chunk", 0)
+
+
+def test_single_sequence_device_wide_sort_vs_oracle(oracle):
+    """Sequences beyond 32 M windows are sorted by the device-wide radix sort (the call then synchronises once to
+    learn the number of keys); the option no_buckets sends a short sequence the same way."""
+    from sequencealigner_amd import capi, minimize, synth
+    g = bytes(synth.genome(250_000, seed=611)) + b"ACGTTGCAAC" * 3000 + b"N" * 50 + bytes(synth.genome(9_000, seed=612))
+    capi.set_option("no_buckets", 1)
+    try:
+        for k, w in ((15, 5), (21, 11), (6, 3)):
+            assert np.array_equal(minimize.minimize_binary(g, k, w), oracle.minimize_binary_array(g, k, w)), (k, w)
+    finally:
+        capi.set_option("no_buckets", 0)
