@@ -471,9 +471,26 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
 
   uint32_t cached_tile = 0xFFFFFFFFu;
-  // 8-symbol windows of the sequences: bytes [base, base + 8) of the blob, base 8-byte aligned
+  // 16-symbol windows of the sequences: bytes [base, base + 16) of the blob, base 16-byte aligned, fetched with
+  // one 16-byte load where that stays within 8 bytes of the pair's end (what the blobs promise), else 8 + 8
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  // The walk moves towards smaller addresses one symbol at a time, so the window below the current one is
+  // fetched as soon as the current one is entered: thousands of threads share a CU and each iteration of a
+  // wavefront would otherwise wait for some lane's window (the kernel is bound by such round trips).
   uint64_t qwin_base = ~0ull, twin_base = ~0ull;
-  uint64_t qwin = 0, twin = 0;
+  u32x4 qwin = {0, 0, 0, 0}, twin = {0, 0, 0, 0}, qnext = {0, 0, 0, 0}, tnext = {0, 0, 0, 0};
+  constexpr uint64_t kNoFetch = ~0ull;
+  uint64_t q_fetch = kNoFetch, t_fetch = kNoFetch;  // window to fetch at the end of this iteration
+  auto load_window = [&](const uint8_t* blob, uint64_t base, uint64_t end) -> u32x4 {
+    if (base + 16 <= end + 8) return *reinterpret_cast<const u32x4*>(blob + base);
+    const uint64_t lo = *reinterpret_cast<const uint64_t*>(blob + base);
+    return u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), 0u, 0u};
+  };
+  auto window_byte = [&](u32x4 w, uint64_t addr) -> uint32_t {
+    const uint32_t d = (uint32_t)(addr >> 2) & 3u;
+    const uint32_t word = d == 0 ? w.x : d == 1 ? w.y : d == 2 ? w.z : w.w;
+    return (word >> (8 * (addr & 3))) & 0xFFu;
+  };
 
   for (;;) {
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
@@ -504,15 +521,19 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
     bool eq = false;
     if (is_diag) {
       const uint64_t qa = qb + rr, ta = tb0 + ii;
-      if ((qa & ~7ull) != qwin_base) {
-        qwin_base = qa & ~7ull;
-        qwin = *reinterpret_cast<const uint64_t*>(a.q + qwin_base);
+      if ((qa & ~15ull) != qwin_base) {
+        const uint64_t base = qa & ~15ull;
+        qwin = (base + 16 == qwin_base) ? qnext : load_window(a.q, base, qb + Q);
+        qwin_base = base;
+        q_fetch = base >= 16 ? base - 16 : kNoFetch;
       }
-      if ((ta & ~7ull) != twin_base) {
-        twin_base = ta & ~7ull;
-        twin = *reinterpret_cast<const uint64_t*>(a.t + twin_base);
+      if ((ta & ~15ull) != twin_base) {
+        const uint64_t base = ta & ~15ull;
+        twin = (base + 16 == twin_base) ? tnext : load_window(a.t, base, tb0 + T);
+        twin_base = base;
+        t_fetch = base >= 16 ? base - 16 : kNoFetch;
       }
-      eq = ((uint32_t)(qwin >> (8 * (qa & 7))) & 0xFFu) == ((uint32_t)(twin >> (8 * (ta & 7))) & 0xFFu);
+      eq = window_byte(qwin, qa) == window_byte(twin, ta);
     }
     const uint32_t op = is_diag ? ((same || eq) ? SA_OP_M : SA_OP_X) : (is_left ? SA_OP_I : SA_OP_D);
     if (MODE == SA_LOCAL) remaining -= is_diag ? (eq ? a.match : a.mismatch) : a.gap;
@@ -527,6 +548,17 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
       }
       cur_op = op;
       cur_len = 1;
+    }
+    // The prefetches go out last, after every use of loaded data in this iteration: a wait placed before such a
+    // use would otherwise wait for them as well.  (The window below the current one ends at or before the
+    // current symbol: a plain 16-byte load stays inside the pair.)
+    if (q_fetch != kNoFetch) {
+      qnext = *reinterpret_cast<const u32x4*>(a.q + q_fetch);
+      q_fetch = kNoFetch;
+    }
+    if (t_fetch != kNoFetch) {
+      tnext = *reinterpret_cast<const u32x4*>(a.t + t_fetch);
+      t_fetch = kNoFetch;
     }
   }
   if (cur_len) {
