@@ -341,10 +341,25 @@ template <int MODE, int K>
 int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
                      AlphabetInfo* alpha, hipStream_t stream, bool need_traceback) {
   const uint32_t units = (a.pairs_in_pass + 127) / 128;
+  // Tables form: the traceback reads the pairs' symbols from per-pair records of 2-bit codes.  They live in the
+  // three quarters of every unit's target area that the one-byte-per-position form leaves unused, when they fit.
+  const uint32_t q_tiles = (a.max_q + kPackTile - 1) / kPackTile, t_tiles = (pl.t_pad + kPackTile - 1) / kPackTile;
+  AlignArgs ar = a;
+  ar.rec = nullptr;
+  uint32_t* rec = nullptr;
+  const uint64_t rec_unit_dwords = 128ull * 4 * (q_tiles + t_tiles);
+  if (alpha && need_traceback && pl.t_pad % 4 == 0 && (uint64_t)pl.t_pad / 4 * 64 + rec_unit_dwords <= pl.tpk_unit_words) {
+    rec = tpk + (uint64_t)pl.t_pad / 4 * 64;
+    ar.rec = rec;
+    ar.rec_unit_stride = pl.tpk_unit_words;
+    ar.rec_stride = 4 * (q_tiles + t_tiles);
+    ar.rec_q_chunks = q_tiles;
+    ar.rec_alpha = alpha;
+  }
   {
     Timed tm(stream, 0);
     PackArgs pk{a.q, a.q_off, a.t, a.t_off, a.pair_base, a.pairs_in_pass, a.max_q, pl.t_pad,
-                (a.max_q + kPackTile - 1) / kPackTile, (pl.t_pad + kPackTile - 1) / kPackTile, qpk, tpk, alpha, 0};
+                q_tiles, t_tiles, qpk, tpk, alpha, 0, rec, pl.tpk_unit_words, 4 * (q_tiles + t_tiles)};
     const dim3 grid((pk.q_tiles + pk.t_tiles + 3) / 4, units);
     hipLaunchKernelGGL(pack_lane_pk16, grid, dim3(256), 0, stream, pk);
     if (alpha) {  // returns at once unless the first launch met a byte the alphabet sample had missed
@@ -368,7 +383,7 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
     {
       Timed tm(stream, 2);
       hipLaunchKernelGGL((traceback_lane_pk16<MODE, K>), dim3((a.pairs_in_pass + kBlock - 1) / kBlock),
-                         dim3(kBlock), 0, stream, a);
+                         dim3(kBlock), 0, stream, ar);
     }
     SA_HIP_TRY(hipGetLastError());
   }

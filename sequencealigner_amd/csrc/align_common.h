@@ -31,6 +31,14 @@ struct AlignArgs {
   uint32_t* cigar_runs;
   uint32_t* cigar_nruns;
   uint64_t cigar_stride;
+  // packed lane kernel, tables form only (else rec == NULL): the pairs' sequences once more as 2-bit codes, one
+  // contiguous record per pair - 16-byte chunks of 64 symbols, rec_q_chunks for the query, then the target's -
+  // for the traceback, which compares symbols of one pair at a time
+  const uint32_t* rec;
+  uint64_t rec_unit_stride;  // dwords between the records of consecutive units of 128 pairs
+  uint32_t rec_stride;       // dwords per pair
+  uint32_t rec_q_chunks;
+  const struct AlphabetInfo* rec_alpha;  // the records are valid when small && !violated
 };
 
 // Border values of the DP matrix, rows = target (index i), columns = query (index r).

@@ -471,25 +471,38 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
 
   uint32_t cached_tile = 0xFFFFFFFFu;
-  // 16-symbol windows of the sequences: bytes [base, base + 16) of the blob, base 16-byte aligned, fetched with
-  // one 16-byte load where that stays within 8 bytes of the pair's end (what the blobs promise), else 8 + 8
+  // Symbols come through 16-byte windows held in registers.  Two sources: the pair's record of 2-bit codes
+  // (a window is 64 symbols; tables form - a million 150 x 300 pairs then fetch 8 windows each instead of 28,
+  // and every miss costs a 128-byte line), or the blobs themselves (a window is 16 bytes, 16-byte aligned in the
+  // blob; fetched with one 16-byte load where that stays within 8 bytes of the pair's end, which is what the
+  // blobs promise, else with an 8-byte load).
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  // The walk moves towards smaller addresses one symbol at a time, so the window below the current one is
+  const bool use_rec = a.rec && a.rec_alpha->small && !a.rec_alpha->violated;  // the same for every thread
+  const uint32_t* myrec =
+      use_rec ? a.rec + (uint64_t)unit * a.rec_unit_stride + (uint64_t)(pl & 127u) * a.rec_stride : nullptr;
+  const uint8_t* qarr = use_rec ? reinterpret_cast<const uint8_t*>(myrec) : a.q;
+  const uint8_t* tarr = use_rec ? reinterpret_cast<const uint8_t*>(myrec + 4 * a.rec_q_chunks) : a.t;
+  const uint64_t qorg = use_rec ? 0 : qb, torg = use_rec ? 0 : tb0;  // index of the pair's first symbol
+  const uint64_t qend = use_rec ? ~0ull >> 8 : qb + Q, tend = use_rec ? ~0ull >> 8 : tb0 + T;  // in bytes
+  const uint32_t wshift = use_rec ? 6 : 4, sbits = use_rec ? 2 : 8, smask = use_rec ? 3u : 0xFFu;
+  // The walk moves towards smaller indices one symbol at a time, so the window below the current one is
   // fetched as soon as the current one is entered: thousands of threads share a CU and each iteration of a
-  // wavefront would otherwise wait for some lane's window (the kernel is bound by such round trips).
-  uint64_t qwin_base = ~0ull, twin_base = ~0ull;
+  // wavefront would otherwise wait for some lane's window.
+  constexpr uint64_t kNoWindow = ~0ull;
+  uint64_t qwin_id = kNoWindow, twin_id = kNoWindow;
   u32x4 qwin = {0, 0, 0, 0}, twin = {0, 0, 0, 0}, qnext = {0, 0, 0, 0}, tnext = {0, 0, 0, 0};
   constexpr uint64_t kNoFetch = ~0ull;
-  uint64_t q_fetch = kNoFetch, t_fetch = kNoFetch;  // window to fetch at the end of this iteration
-  auto load_window = [&](const uint8_t* blob, uint64_t base, uint64_t end) -> u32x4 {
-    if (base + 16 <= end + 8) return *reinterpret_cast<const u32x4*>(blob + base);
-    const uint64_t lo = *reinterpret_cast<const uint64_t*>(blob + base);
+  uint64_t q_fetch = kNoFetch, t_fetch = kNoFetch;  // byte offset of the window to fetch at the end of this iteration
+  auto load_window = [&](const uint8_t* arr, uint64_t base, uint64_t end) -> u32x4 {
+    if (base + 16 <= end + 8) return *reinterpret_cast<const u32x4*>(arr + base);
+    const uint64_t lo = *reinterpret_cast<const uint64_t*>(arr + base);
     return u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), 0u, 0u};
   };
-  auto window_byte = [&](u32x4 w, uint64_t addr) -> uint32_t {
-    const uint32_t d = (uint32_t)(addr >> 2) & 3u;
+  auto window_symbol = [&](u32x4 w, uint64_t index) -> uint32_t {
+    const uint32_t bit = ((uint32_t)index & ((1u << wshift) - 1u)) * sbits;
+    const uint32_t d = bit >> 5;
     const uint32_t word = d == 0 ? w.x : d == 1 ? w.y : d == 2 ? w.z : w.w;
-    return (word >> (8 * (addr & 3))) & 0xFFu;
+    return (word >> (bit & 31u)) & smask;
   };
 
   for (;;) {
@@ -520,20 +533,20 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
     const bool is_left = interior ? (not_diag && !not_left) : (i == 0);
     bool eq = false;
     if (is_diag) {
-      const uint64_t qa = qb + rr, ta = tb0 + ii;
-      if ((qa & ~15ull) != qwin_base) {
-        const uint64_t base = qa & ~15ull;
-        qwin = (base + 16 == qwin_base) ? qnext : load_window(a.q, base, qb + Q);
-        qwin_base = base;
-        q_fetch = base >= 16 ? base - 16 : kNoFetch;
+      const uint64_t qa = qorg + rr, ta = torg + ii;
+      if ((qa >> wshift) != qwin_id) {
+        const uint64_t id = qa >> wshift;
+        qwin = (id + 1 == qwin_id) ? qnext : load_window(qarr, id * 16, qend);
+        qwin_id = id;
+        q_fetch = id ? (id - 1) * 16 : kNoFetch;
       }
-      if ((ta & ~15ull) != twin_base) {
-        const uint64_t base = ta & ~15ull;
-        twin = (base + 16 == twin_base) ? tnext : load_window(a.t, base, tb0 + T);
-        twin_base = base;
-        t_fetch = base >= 16 ? base - 16 : kNoFetch;
+      if ((ta >> wshift) != twin_id) {
+        const uint64_t id = ta >> wshift;
+        twin = (id + 1 == twin_id) ? tnext : load_window(tarr, id * 16, tend);
+        twin_id = id;
+        t_fetch = id ? (id - 1) * 16 : kNoFetch;
       }
-      eq = window_byte(qwin, qa) == window_byte(twin, ta);
+      eq = window_symbol(qwin, qa) == window_symbol(twin, ta);
     }
     const uint32_t op = is_diag ? ((same || eq) ? SA_OP_M : SA_OP_X) : (is_left ? SA_OP_I : SA_OP_D);
     if (MODE == SA_LOCAL) remaining -= is_diag ? (eq ? a.match : a.mismatch) : a.gap;
@@ -553,11 +566,11 @@ __global__ __launch_bounds__(256) void traceback_lane_pk16(AlignArgs a) {
     // use would otherwise wait for them as well.  (The window below the current one ends at or before the
     // current symbol: a plain 16-byte load stays inside the pair.)
     if (q_fetch != kNoFetch) {
-      qnext = *reinterpret_cast<const u32x4*>(a.q + q_fetch);
+      qnext = *reinterpret_cast<const u32x4*>(qarr + q_fetch);
       q_fetch = kNoFetch;
     }
     if (t_fetch != kNoFetch) {
-      tnext = *reinterpret_cast<const u32x4*>(a.t + t_fetch);
+      tnext = *reinterpret_cast<const u32x4*>(tarr + t_fetch);
       t_fetch = kNoFetch;
     }
   }
@@ -654,6 +667,10 @@ struct PackArgs {
   uint32_t* tpk;
   AlphabetInfo* alpha;
   uint32_t again;  // 1: the launch that repeats the packing in the symbols form if `violated` was raised
+  // tables form: per-pair records of 2-bit codes for the traceback (AlignArgs::rec); NULL: none
+  uint32_t* rec;
+  uint64_t rec_unit_stride;
+  uint32_t rec_stride;
 };
 
 __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
@@ -714,6 +731,7 @@ __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
     // one byte per position (nibbles: pair A, pair B), four positions per dword
     uint32_t* out4 = (is_query ? a.qpk : a.tpk) + ((uint64_t)unit * len_cap + t0 / 4) * 64 + lane;
     const uint32_t padn = is_query ? 0xFu : 0xCu, addb = is_query ? 0u : 4u;
+    uint32_t reca[4] = {0, 0, 0, 0}, recb[4] = {0, 0, 0, 0};  // the tile's 64 codes of either pair, 2 bits each
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
       uint64_t ra = wa[j], rb = wb[j];
@@ -721,7 +739,7 @@ __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
       for (uint32_t g = 0; g < 2; ++g) {
         const uint32_t c0 = 8 * j + 4 * g;
         if (t0 + c0 >= len_cap) break;
-        uint32_t v = 0;
+        uint32_t v = 0, ha = 0, hb = 0;
 #pragma unroll
         for (uint32_t x = 0; x < 4; ++x, ra >>= 8, rb >>= 8) {
           const uint32_t pos = t0 + c0 + x;
@@ -731,9 +749,21 @@ __global__ __launch_bounds__(256) void pack_lane_pk16(PackArgs a) {
           unseen |= ca | cb;
           const uint32_t na = inA ? (ca & 3u) : padn, nb = inB ? addb + (cb & 3u) : padn;
           v |= (na | (nb << 4)) << (8 * x);
+          ha |= (ca & 3u) << (2 * x);
+          hb |= (cb & 3u) << (2 * x);
         }
         __builtin_nontemporal_store(v, &out4[(uint64_t)(c0 / 4) * 64]);  // read once, by the fill, much later
+        reca[j / 2] |= ha << (16 * (j & 1) + 8 * g);
+        recb[j / 2] |= hb << (16 * (j & 1) + 8 * g);
       }
+    }
+    if (a.rec) {  // chunk of this tile: query chunks first, then the target's
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      uint32_t* r0 = a.rec + (uint64_t)unit * a.rec_unit_stride + (uint64_t)tile * 4;
+      if (plA < a.pairs_in_pass)
+        *reinterpret_cast<u32x4*>(r0 + (uint64_t)lane * a.rec_stride) = u32x4{reca[0], reca[1], reca[2], reca[3]};
+      if (plB < a.pairs_in_pass)
+        *reinterpret_cast<u32x4*>(r0 + (uint64_t)(lane + 64) * a.rec_stride) = u32x4{recb[0], recb[1], recb[2], recb[3]};
     }
   }
   if (unseen & kUnseen) a.alpha->violated = 1;
