@@ -86,7 +86,11 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint32_t (*bufv)[kT
   uint64_t* dst = a.keys + slot + base + (excl - run_begin);
   for (int i = 0; i < kBuf; ++i) {
     if (!__any((uint32_t)i < cnt)) break;
-    if ((uint32_t)i < cnt) dst[i] = ((uint64_t)bufv[i][tid] << a.key_shift) | bufp[i][tid];
+    if ((uint32_t)i < cnt) {
+      const uint64_t key = ((uint64_t)bufv[i][tid] << a.key_shift) | bufp[i][tid];
+      dst[i] = key;
+      if (a.hist) atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u);
+    }
   }
   cnt = 0;
 }
@@ -213,10 +217,13 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
 }
 
 // Before the exact machine runs a batch again: forget the keys and the unresolved chunks of the first run.
-__global__ void min_redo_reset(uint32_t* counter, uint32_t n, const uint32_t* other) {
+__global__ void min_redo_reset(uint32_t* counter, uint32_t n, const uint32_t* other, uint32_t* hist,
+                               uint32_t hist_words) {
   if (*other == 0) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n) counter[i] = 0;  // n counters and the count of unresolved chunks behind them
+  if (hist)                    // (single-sequence calls) the keys counted so far
+    for (uint32_t x = i; x < hist_words; x += gridDim.x * blockDim.x) hist[x] = 0;
 }
 
 // One wave per sequence, only when some chunk's candidate set did not collapse: those chunks take their
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n
           const uint64_t key = m.key(a.key_shift);
           if (key != last) {
             out[n_out++] = key;
+            if (a.hist) atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u);
             last = key;
           }
         }
@@ -872,7 +880,8 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
 // ---- one long sequence: its keys are cut into value-ordered buckets of about kBucketKeys keys, which
 // sort_emit_small then sorts, de-duplicates and writes like the reads of a batch - five launches instead of a
 // device-wide radix sort's twenty-odd, which is what a call on a single genome-sized sequence costs.
-//   bucket_hist     counts the keys per fine bin (the top kFineBits bits of the key's significant bits)
+//   (min_run / min_fix count the keys per fine bin - the top kFineBits bits of a key's significant bits -
+//   as they write them)
 //   bucket_plan     one block: exclusive prefix P of the counts (left in place as the scatter's cursors);
 //                   bucket of a fine bin = P >> 10, so buckets are runs of whole fine bins and hold at most
 //                   kBucketKeys keys plus one fine bin; writes every bucket's key range and fine-bin range
@@ -883,9 +892,6 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
 constexpr uint32_t kFineBits = 16, kFine = 1u << kFineBits;
 constexpr uint32_t kBucketShift = 10, kBucketKeys = 1u << kBucketShift;
 constexpr uint32_t kNoBin = 0xFFFFFFFFu;
-// where fine bin f's counter lives: transposed, so that bucket_plan, whose thread t owns the bins
-// t * 256 .. t * 256 + 255, reads and writes the array in coalesced lines
-__device__ __forceinline__ uint32_t fine_slot(uint32_t f) { return ((f & 255u) << 8) | (f >> 8); }
 
 struct BucketArgs {
   const uint64_t* keys;     // the sequence's keys as min_run left them
@@ -903,12 +909,6 @@ struct BucketArgs {
   uint64_t* seg_span;
 };
 
-__global__ __launch_bounds__(kThreads) void bucket_hist(BucketArgs a) {
-  const uint32_t n = *a.count;
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-    atomicAdd(&a.hist[fine_slot((uint32_t)(a.keys[i] >> a.fine_shift))], 1u);
-}
-
 __global__ __launch_bounds__(kThreads) void bucket_plan(BucketArgs a) {
   __shared__ uint32_t lds[kThreads / 64];
   __shared__ uint32_t last_start[kThreads], last_bin[kThreads];
@@ -917,14 +917,18 @@ __global__ __launch_bounds__(kThreads) void bucket_plan(BucketArgs a) {
   const uint32_t tid = threadIdx.x, base = tid * kPer;
   // thread t owns the fine bins base .. base + 255, stored at e * 256 + t
   uint32_t sum = 0, lb = kNoBin, ls = 0;
-#pragma unroll 16
-  for (uint32_t e = 0; e < kPer; ++e) {
-    const uint32_t c = a.hist[e * kThreads + tid];
-    if (c) {
-      lb = base + e;
-      ls = sum;  // (relative to the thread's first key)
+  for (uint32_t e0 = 0; e0 < kPer; e0 += 32) {  // 32 loads in flight at a time
+    uint32_t cs[32];
+#pragma unroll
+    for (uint32_t x = 0; x < 32; ++x) cs[x] = a.hist[(e0 + x) * kThreads + tid];
+#pragma unroll
+    for (uint32_t x = 0; x < 32; ++x) {
+      if (cs[x]) {
+        lb = base + e0 + x;
+        ls = sum;  // (relative to the thread's first key)
+      }
+      sum += cs[x];
     }
-    sum += c;
   }
   uint32_t excl;
   const uint32_t total = block_sum(sum, lds, &excl);
@@ -1290,6 +1294,8 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.keys = keys;
   a.status = b->d_status;
   a.other = other;
+  a.hist = pl.buckets ? (uint32_t*)(ws + pl.o_hist) : nullptr;
+  a.fine_shift = pl.fine_shift;
   auto blocks = [](uint64_t items) { return dim3((unsigned)((items + kThreads - 1) / kThreads)); };
   size_t t = 0;
   if (pl.buckets) {  // one sequence: the bookkeeping in one launch, the bucket tables cleared alongside
@@ -1321,7 +1327,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     // a batch with bytes other than bases runs again on the exact machine (the three kernels return at
     // once otherwise)
     hipLaunchKernelGGL(min_redo_reset, blocks((uint64_t)b->n + 1), dim3(kThreads), 0, stream, counter, b->n,
-                       other);
+                       other, a.hist, kFine);
     auto* run_x = long_k ? min_run<MachineX<true>> : min_run<MachineX<false>>;
     auto* fix_x = long_k ? min_fix<MachineX<true>> : min_fix<MachineX<false>>;
     hipLaunchKernelGGL(run_x, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
@@ -1345,8 +1351,8 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ba.seg_lokey = (uint64_t*)(ws + pl.o_bseg_lokey);
     ba.seg_span = (uint64_t*)(ws + pl.o_bseg_span);
     ba.nseg_used = (uint32_t*)((uint64_t*)(ws + pl.o_bscan) + pl.nseg + 1);
-    const dim3 sweep((unsigned)std::min<uint64_t>((pl.capacity + 4 * kThreads - 1) / (4 * kThreads), 2048));
-    hipLaunchKernelGGL(bucket_hist, sweep, dim3(kThreads), 0, stream, ba);
+    // (one key per thread where the grid allows: the scatter is a chain of atomics that return a value)
+    const dim3 sweep((unsigned)std::min<uint64_t>(pl.capacity / (2 * kThreads) + 1, 65535));
     hipLaunchKernelGGL(bucket_plan, dim3(1), dim3(kThreads), 0, stream, ba);
     hipLaunchKernelGGL(bucket_scatter, sweep, dim3(kThreads), 0, stream, ba);
     hipLaunchKernelGGL(bucket_split, dim3(pl.nseg), dim3(kThreads), 0, stream, ba);

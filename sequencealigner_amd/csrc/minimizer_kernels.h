@@ -59,7 +59,15 @@ struct MinArgs {
   uint64_t* keys;              // candidate keys; sequence s owns [wbase[s], wbase[s] + counter[s])
   int* status;
   uint32_t* other;             // set to 1 by a thread that met a byte other than ACGT / acgt
+  // single-sequence calls: every key written is also counted in the histogram of the bucketed sort
+  // (kFine counters, slot fine_slot(key >> fine_shift)); NULL otherwise
+  uint32_t* hist;
+  uint32_t fine_shift;
 };
+
+// where fine bin f's counter lives: transposed, so that bucket_plan, whose thread t owns the bins
+// t * 256 .. t * 256 + 255, reads and writes the array in coalesced lines
+__device__ __forceinline__ uint32_t fine_slot(uint32_t f) { return ((f & 255u) << 8) | (f >> 8); }
 
 // forward-strand code of an ASCII base: C0 A1 T2 G3 (either case).  (c >> 1) & 3 gives A0 C1 T2 G3.
 __device__ __forceinline__ uint32_t base_code(uint32_t c) {
