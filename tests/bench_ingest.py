@@ -3,7 +3,7 @@ as one FASTA record (80 columns) and 10 kbp reads as FASTQ, 1 Gbp in all.  Print
 whole-call time (two kernels, a scan and two stream synchronisations), file GB/s, and the CPU restatement's
 single-thread rate on a sample of the same bytes.
 
-    python tools/ingestbench.py [--reads 100000] [--cpu-mb 64]
+    python tests/bench_ingest.py [--reads 100000] [--cpu-mb 64]
 """
 import argparse
 import json

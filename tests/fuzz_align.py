@@ -2,7 +2,7 @@
 strip, tile and lane-block sizes of the kernels), random scoring schemes inside the reference's defined
 envelope, small alphabets, every kernel family.  Prints one line per batch and stops at the first mismatch.
 
-    python tools/fuzz_align.py [--seconds 120] [--seed 1]
+    python tests/fuzz_align.py [--seconds 120] [--seed 1]
 """
 import argparse
 import os

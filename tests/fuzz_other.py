@@ -5,7 +5,7 @@ homopolymers (which defeat the warm-up), bytes other than bases, batches of mixe
 Ingest: FASTA / FASTQ files from the generators of the tests, then damaged at random (bytes overwritten,
 inserted or removed, truncated): both sides must accept the same files and agree on every output.
 
-    python tools/fuzz_other.py [--seconds 120] [--seed 1]
+    python tests/fuzz_other.py [--seconds 120] [--seed 1]
 """
 import argparse
 import os
