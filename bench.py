@@ -458,7 +458,7 @@ def main():
     world = sdist.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    dev = world.local_rank if world.is_dist else 0
+    dev = sdist.device_of(world)
     torch.cuda.set_device(dev)
     lib = capi.lib()
     threads = args.cpu_threads or host_cores()[0]

@@ -22,19 +22,31 @@ class World:
 
 
 def init(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (set by torch.distributed.run)."""
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (set by torch.distributed.run).
+    SA_DIST_BACKEND=gloo forces the CPU backend on a GPU box: the way to rehearse several ranks on a box with
+    one GPU, where RCCL refuses two ranks on the same device (the ranks then share device 0, see device_of)."""
     size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if size > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=size)
     return World(rank, size, local_rank, backend)
+
+
+def device_of(world):
+    """Index of the GPU this rank computes on: its local rank; under gloo on a box with fewer GPUs than ranks
+    (a rehearsal) the ranks wrap around the GPUs there are."""
+    if not world.is_dist:
+        return 0
+    if world.backend == "gloo":
+        return world.local_rank % max(torch.cuda.device_count(), 1)
+    return world.local_rank
 
 
 def barrier(world):
