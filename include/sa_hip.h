@@ -71,6 +71,12 @@ const char* sa_device_arch(int device);
  *   "min_chunk"     (SA_MIN_CHUNK)     windows per minimizer chunk, 0 automatic
  *   "no_buckets"    (SA_NO_BUCKETS)    1: a single sequence is sorted by the device-wide radix sort, as sequences
  *                                      beyond 32 M windows always are
+ *   "no_segments"   (SA_NO_SEGMENTS)   1: the path of a long Global / Semiglobal pair is walked by one wavefront,
+ *                                      not by one wavefront per segment of target rows
+ *   "seg_rows"      (SA_SEG_ROWS)      target rows per such segment, 0 automatic (1024, more for targets
+ *                                      beyond 1 M rows)
+ *   "seg_cap"       (SA_SEG_CAP)       runs a segment may hold, 0: its share of the pair's run slot; a small
+ *                                      value sends pairs to the one-wavefront walk (a test hook)
  *   "fake_devices"  (SA_FAKE_DEVICES)  the host batch calls deal their units to this many shards, all run on
  *                                      GPU 0 at the same time (the multi-GPU path on a one-GPU machine)
  * A call that is planning a batch while an option changes may see either value; set options between calls. */

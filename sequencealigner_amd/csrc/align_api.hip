@@ -5,6 +5,7 @@
 #include "align_wave_i32.h"
 #include "align_wave_pk16.h"
 #include "align_wave_coop.h"
+#include "align_wave_segments.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -46,6 +47,9 @@ Options& options() {
     x->pk16_k = num("SA_PK16_K", 48);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
+    x->no_segments = num("SA_NO_SEGMENTS", 0);
+    x->seg_rows = num("SA_SEG_ROWS", 0);
+    x->seg_cap = num("SA_SEG_CAP", 0);
     x->fake_devices = num("SA_FAKE_DEVICES", 0);
     return x;
   }();
@@ -437,8 +441,38 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
     }
     SA_HIP_TRY(hipGetLastError());
     if (need_traceback) {
-      {
-        Timed tm(stream, 2);
+      // Long pairs: the path is walked by one wavefront per segment of target rows (align_wave_segments.h), the
+      // state of the segments in the boundary area, which the fill has finished with.
+      const Options& opt = options();
+      uint32_t rows = opt.seg_rows > 0 ? (uint32_t)round_up((size_t)opt.seg_rows, 64) : 1024;
+      rows = std::max<uint32_t>(rows, (uint32_t)round_up(((size_t)a.max_t + kMaxSegments - 1) / kMaxSegments, 64));
+      const uint32_t nseg = (a.max_t + rows - 1) / rows;
+      const size_t state_words = seg_state_words(a.pairs_in_pass, nseg) + 1;
+      const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 8 && a.cigar_stride / nseg >= 64 &&
+                            a.cigar_stride / nseg <= 0xFFFFFFFFull &&
+                            state_words <= (size_t)a.pairs_in_pass * a.brow_unit_stride &&
+                            (size_t)a.pairs_in_pass * nseg < ((size_t)1 << 31);
+      Timed tm(stream, 2);
+      if (segments) {
+        SegArgs sg{};
+        sg.rows = rows;
+        sg.nseg = nseg;
+        sg.cap = (uint32_t)(a.cigar_stride / nseg);
+        if (opt.seg_cap > 0 && (uint64_t)opt.seg_cap < sg.cap) sg.cap = (uint32_t)opt.seg_cap;
+        sg.pub = reinterpret_cast<uint64_t*>(a.brow);
+        sg.seg_nruns = reinterpret_cast<uint32_t*>(sg.pub + (size_t)a.pairs_in_pass * nseg);
+        sg.redo = sg.seg_nruns + (size_t)a.pairs_in_pass * nseg;
+        sg.ticket = sg.redo + a.pairs_in_pass;
+        sg.abort_flag = co.abort_flag;
+        hipLaunchKernelGGL(clear_words, dim3((unsigned)((state_words + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<uint32_t*>(a.brow), (uint32_t)state_words);
+        hipLaunchKernelGGL((traceback_wave_segments<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass * nseg), dim3(64), 0,
+                           stream, a, sg);
+        hipLaunchKernelGGL((stitch_segments<MODE>), dim3(a.pairs_in_pass), dim3(1024), 0, stream, a, sg);
+        AlignArgs ar = a;  // pairs whose segments ran out of room: one wavefront each, from the start
+        ar.tb_only = sg.redo;
+        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, ar);
+      } else {
         hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
       }
       SA_HIP_TRY(hipGetLastError());
@@ -516,7 +550,8 @@ int sa_set_option(const char* name, long value) {
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
-               {"no_buckets", &o.no_buckets}};
+               {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
+               {"seg_cap", &o.seg_cap}};
   for (auto& e : table)
     if (!strcmp(name, e.name)) {
       *e.slot = value;

@@ -39,6 +39,8 @@ struct AlignArgs {
   uint32_t rec_stride;       // dwords per pair
   uint32_t rec_q_chunks;
   const struct AlphabetInfo* rec_alpha;  // the records are valid when small && !violated
+  // traceback_wave: when set, only the pairs (of the pass) with a nonzero word are walked
+  const uint32_t* tb_only;
 };
 
 // Border values of the DP matrix, rows = target (index i), columns = query (index r).

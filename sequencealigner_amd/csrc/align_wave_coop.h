@@ -33,6 +33,8 @@ namespace sa {
 constexpr uint32_t kCoopBatch = 16;  // steps per batch = rows per hand-over to the next strip
 constexpr uint32_t kCoopFetch = 32;  // rows a strip fetches at a time (two batches): the wait for a fetch also
                                      // waits for every store issued before it, so it should come rarely and late
+constexpr uint32_t kCoopRing = 128;  // rows of target symbols a strip keeps at hand: lane 63 is 63 rows behind
+                                     // lane 0, which has up to two fetches before it
 
 // steps a strip's direction words are laid out for: every step up to max_t + 63, whole batches, plus the
 // one extra batch in which the last boundary rows are handed over
@@ -66,6 +68,12 @@ template <int MODE, int C>
 __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, uint32_t tables) {
   static_assert(MODE != SA_LOCAL, "Global and Semiglobal only");
   __shared__ uint32_t seen[64];  // byte values of the strip's query columns and the target; then their codes
+  // Inputs and outputs of the steps travel through LDS, one access with a constant offset per step each:
+  __shared__ int trows[2 * kCoopRing];        // target symbol (tables: row word) of the last kCoopRing rows, row i at
+                                              // i % kCoopRing and again kCoopRing further on: 16 rows from any start
+                                              // are contiguous
+  __shared__ int bleft[2 * kCoopFetch];       // left boundary values of the current and the next kCoopFetch rows
+  __shared__ int lastcols[kCoopBatch * 64];   // every lane's last-column value of the 16 steps of a batch
   constexpr uint32_t STRIP = 64 * C;
   constexpr uint32_t SPW = 16 / C;
   constexpr uint32_t B = kCoopBatch;
@@ -135,13 +143,11 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
   }
   int ldiag = border_row0<MODE>((int)c0, gap) + gap;  // H[i-1][c0] + gap for the lane's first row
   int lastcol = 0;                                    // H[i][c0 + C] + gap of the row just computed
-  int tc = TAB ? 0 : 256;                             // target symbol (tables: row word) of the lane's current row
-  int bout = 0;                                       // shift register of lane 63's results
   uint32_t acc = 0;                                   // direction flags of the last SPW steps
   const uint32_t steps = T + 63;
 
-  // Inputs of lane 0 for the 32 steps of two batches, one per lane 0..31: the target symbol of row b0 + L and
-  // the entry of the left boundary column for that row.
+  // Inputs of the 32 steps of two batches, fetched by lanes 0..31: the target symbol of row b0 + L and the entry
+  // of the left boundary column for that row.
   auto want_row = [&](uint32_t b0) { return lane < kCoopFetch && b0 + lane <= T; };
   auto load_syms = [&](uint32_t b0) -> int { return want_row(b0) ? (int)t[b0 + lane - 1] : 256; };
   // tables: symbols -> row words, once the loads have arrived
@@ -170,21 +176,32 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
     }
     return true;
   };
+  // hands the fetched rows b0 .. b0 + 31 (b0 = 1 + 32 m) to the steps
+  auto stage_rows = [&](uint32_t b0, int words, int entry) __attribute__((always_inline)) {
+    if (lane < kCoopFetch) {
+      const uint32_t at = (b0 + lane) % kCoopRing;
+      trows[at] = words;
+      trows[at + kCoopRing] = words;
+      bleft[(((b0 - 1) / kCoopFetch) & 1u) * kCoopFetch + lane] = entry;
+    }
+  };
 
   // One step at position X of its batch.  FULL: every lane has a valid row, nothing is predicated.
   // TRACK: Semiglobal's last strip, which follows the last column's maximum row by row.
-  // H: which half of the fetched rows the batch uses.
-  auto step = [&](uint32_t b0, auto x_tag, auto half_tag, auto full_tag, auto track_tag, int bcur, int tcur)
-                  __attribute__((always_inline)) {
+  // tp: the lane's target rows of this batch, bp: lane 0's left values of the batch; tc / bl arrive one step ahead.
+  auto step = [&](uint32_t b0, auto x_tag, auto full_tag, auto track_tag, const int* tp, const int* bp, int& tc_next,
+                  int& bl_next) __attribute__((always_inline)) {
     constexpr uint32_t X = decltype(x_tag)::value;
-    constexpr uint32_t HALF = decltype(half_tag)::value;
-    constexpr uint32_t XF = X + HALF * B;  // position among the fetched rows
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr bool TRACK = decltype(track_tag)::value;
     const uint32_t st = b0 + X;
-    // lane 0 takes its inputs from the batch registers, every other lane from the lane below
-    tc = dpp_shr1(__builtin_amdgcn_readlane(tcur, XF), tc);
-    const int recv = dpp_shr1(__builtin_amdgcn_readlane(bcur, XF), lastcol);
+    const int tc = tc_next;
+    // lane 0 takes the boundary value, every other lane the value of the lane below
+    const int recv = dpp_shr1(bl_next, lastcol);
+    if (X + 1 < B) {
+      tc_next = tp[X + 1];
+      bl_next = bp[X + 1];
+    }
     uint32_t bits = FULL ? acc : 0u;
     const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
     if (FULL || (st > lane && i <= T)) {
@@ -222,13 +239,16 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
       }
     }
     acc = FULL ? bits : ((acc << (2 * C)) | bits);
-    bout = dpp_shl1(lastcol, bout);  // lane 63 puts in its newest value, the others move down one lane
+    lastcols[X * 64 + lane] = lastcol;  // lane 63's are the rows handed to the next strip
     if (X % SPW == SPW - 1)  // written once, read once by the traceback: keep it out of the caches
       __builtin_nontemporal_store(acc, dw + (uint64_t)((st - 1) / SPW) * 64);
   };
-  auto batch = [&](uint32_t b0, auto half_tag, auto full_tag, auto track_tag, int bcur, int tcur)
-                   __attribute__((always_inline)) {
-#define SA_COOP_STEP(X) step(b0, std::integral_constant<uint32_t, X>{}, half_tag, full_tag, track_tag, bcur, tcur);
+  // One batch of 16 steps starting at step b0; half: which half of the fetched rows it uses.
+  auto batch = [&](uint32_t b0, uint32_t half, auto full_tag, auto track_tag) __attribute__((always_inline)) {
+    const int* tp = trows + ((b0 - lane) % kCoopRing);
+    const int* bp = bleft + ((((b0 - 1) / kCoopFetch) & 1u) * kCoopFetch + half * B);
+    int tc_next = tp[0], bl_next = bp[0];
+#define SA_COOP_STEP(X) step(b0, std::integral_constant<uint32_t, X>{}, full_tag, track_tag, tp, bp, tc_next, bl_next);
     SA_COOP_STEP(0) SA_COOP_STEP(1) SA_COOP_STEP(2) SA_COOP_STEP(3) SA_COOP_STEP(4) SA_COOP_STEP(5)
     SA_COOP_STEP(6) SA_COOP_STEP(7) SA_COOP_STEP(8) SA_COOP_STEP(9) SA_COOP_STEP(10) SA_COOP_STEP(11)
     SA_COOP_STEP(12) SA_COOP_STEP(13) SA_COOP_STEP(14) SA_COOP_STEP(15)
@@ -236,47 +256,45 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
   };
 
   auto publish = [&](uint32_t b0) __attribute__((always_inline)) {
-    // lane 63 finished rows up to b0 + 15 - 63; rows b0-64 .. b0-49 are in lanes 47..62
+    // lane 63 finished the rows b0 - 63 .. b0 - 48 in this batch; lanes 47..62 pick them up and store them
     if (!last_strip) {
-      const uint32_t row = b0 + lane - 111;  // lane 62 holds row b0 + 15 - 63 - 1
-      if (lane >= 47 && lane <= 62 && b0 + lane >= 112 && row <= T)
-        __hip_atomic_store(&bout_p[row], ((uint64_t)(s + 1) << 32) | (uint32_t)bout, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t row = b0 + lane - 110;
+      if (lane >= 47 && lane <= 62 && b0 + lane >= 111 && row <= T)
+        __hip_atomic_store(&bout_p[row], ((uint64_t)(s + 1) << 32) | (uint32_t)lastcols[(lane - 47) * 64 + 63],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   // One batch of 16 steps.
-  auto run_batch = [&](uint32_t b0, auto half_tag, int bcur, int tcur) __attribute__((always_inline)) {
+  auto run_batch = [&](uint32_t b0, uint32_t half) __attribute__((always_inline)) {
     const bool full = b0 >= 64 && b0 + B - 1 <= T;
     if (MODE == SA_SEMIGLOBAL && last_strip) {
       if (full)
-        batch(b0, half_tag, std::true_type{}, std::true_type{}, bcur, tcur);
+        batch(b0, half, std::true_type{}, std::true_type{});
       else
-        batch(b0, half_tag, std::false_type{}, std::true_type{}, bcur, tcur);
+        batch(b0, half, std::false_type{}, std::true_type{});
     } else {
       if (full)
-        batch(b0, half_tag, std::true_type{}, std::false_type{}, bcur, tcur);
+        batch(b0, half, std::true_type{}, std::false_type{});
       else
-        batch(b0, half_tag, std::false_type{}, std::false_type{}, bcur, tcur);
+        batch(b0, half, std::false_type{}, std::false_type{});
     }
   };
 
   uint64_t e_cur = load_entries(1);
   int t_cur = load_syms(1);
   if (!poll_entries(1, e_cur)) return false;
-  t_cur = row_words(t_cur);
-  // up to one batch beyond the last step: the shift register needs it to deliver the last rows of the boundary
+  stage_rows(1, row_words(t_cur), (int)(uint32_t)e_cur);
+  // up to one batch beyond the last step, in which the last rows of the boundary are handed over
   for (uint32_t b0 = 1; b0 <= steps + B; b0 += kCoopFetch) {
     // fetch the inputs of the next two batches now, look at them after this pair of batches
     uint64_t e_next = load_entries(b0 + kCoopFetch);
     const int t_next = load_syms(b0 + kCoopFetch);
-    const int bcur = (int)(uint32_t)e_cur;
-    run_batch(b0, std::integral_constant<uint32_t, 0>{}, bcur, t_cur);
+    run_batch(b0, 0);
     publish(b0);
-    run_batch(b0 + B, std::integral_constant<uint32_t, 1>{}, bcur, t_cur);
+    run_batch(b0 + B, 1);
     publish(b0 + B);
     if (!poll_entries(b0 + kCoopFetch, e_next)) return false;
-    e_cur = e_next;
-    t_cur = row_words(t_next);
+    stage_rows(b0 + kCoopFetch, row_words(t_next), (int)(uint32_t)e_next);
   }
   {  // Global: a lane's registers keep the values of its last row, H[T][column] + gap
     uint32_t pick = 0;

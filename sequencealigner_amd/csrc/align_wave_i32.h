@@ -456,12 +456,22 @@ struct WaveFmtI32 {
   }
 };
 
-// Traceback + run-length encoding for the wavefront layouts, one wavefront per pair (same rules as
+// What a walk leaves behind: the number of runs written, the cell it stopped at, the run that ended the walk
+// (the first of the CIGAR) and whether the runs outgrew the room they were given.
+struct WalkEnd {
+  uint32_t nruns, i, r, last_op, last_len;
+  bool overflow;
+};
+
+// Traceback + run-length encoding for the wavefront layouts by one wavefront (same rules as
 // traceback_kernel).  The direction words of kTileSteps consecutive steps of a strip are one contiguous
 // block: the wave copies that block, the strip's query symbols and the target symbols of the rows it
-// spans into LDS and walks inside it; every lane follows the same path, lane 0 writes the runs.
+// spans into LDS and walks inside it; every lane follows the same path, the runs leave one per lane.
+// The walk starts at cell (i, r) and stops where the path ends or, with lo > 0, at the first cell of row lo
+// (no move is taken from that cell).  Runs are written backwards from slot_end, at most `cap` of them.
 template <int MODE, class Fmt>
-__global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
+__device__ __forceinline__ WalkEnd walk_wave(const AlignArgs& a, uint32_t pl, uint32_t i, uint32_t r, uint32_t lo,
+                                             uint32_t* slot_end, uint32_t cap) {
   using word_t = typename Fmt::word_t;
   constexpr int C = Fmt::C;
   constexpr uint32_t STRIP = 64 * C;
@@ -478,8 +488,6 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   __shared__ uint8_t qs[STRIP];
   __shared__ uint8_t ts[TS + 64];
   const uint32_t lane = threadIdx.x;
-  const uint32_t pl = blockIdx.x;
-  if (pl >= a.pairs_in_pass) return;
   const uint32_t p = a.pair_base + pl;
   const uint32_t half = pl % Fmt::kPairs;
   const uint8_t* q = a.q + a.q_off[p];
@@ -489,17 +497,16 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   const word_t* dirs =
       reinterpret_cast<const word_t*>(a.dirs + (uint64_t)(pl / Fmt::kPairs) * a.dirs_unit_stride);
   const uint32_t nrows = Fmt::rows(a.max_t);
-  uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
-  uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
   const bool same = (a.match == a.mismatch);
-  uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
+  bool overflow = false;
   uint32_t nruns = 0, cur_op = 4, cur_len = 0;
   int remaining = (MODE == SA_LOCAL) ? a.score[p] : 1;
   // Finished runs wait in `runbuf`, one per lane, and leave with one store per iteration: the walk is a chain
   // of scalar instructions on one wavefront, a store per run (address, lane mask) was a good part of it.
   uint32_t runbuf = 0, nbuf = 0;
   auto flush_runs = [&]() __attribute__((always_inline)) {
-    if (slot_end && lane < nbuf) slot_end[-(int64_t)(nruns + 1 + lane)] = runbuf;
+    if (nruns + nbuf > cap) overflow = true;
+    if (slot_end && !overflow && lane < nbuf) slot_end[-(int64_t)(nruns + 1 + lane)] = runbuf;
     nruns += nbuf;
     nbuf = 0;
   };
@@ -537,13 +544,14 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
     return reinterpret_cast<const u32x4*>(dirs + ((uint64_t)s * nrows + lo / SPW + row) * 64 + lb) + colv;
   };
   for (;;) {
+    if (lo && i <= lo) break;
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
     uint32_t d;
     uint32_t len = 1;  // moves of kind d taken in this iteration
     if (i == 0 || r == 0) {
-      d = border_dir<MODE>(i, r, a.gap);  // None, Left or Up
-      len = (d == DIR_LEFT) ? r : i;      // a border is followed to its end
+      d = border_dir<MODE>(i, r, a.gap);   // None, Left or Up
+      len = (d == DIR_LEFT) ? r : i - lo;  // a border is followed to its end
     } else {
       if (MODE == SA_LOCAL && remaining == 0) break;  // an inner cell with score 0 is None
       const uint32_t c = r - 1;
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
       // Lane x looks at the cell x steps further along the diagonal, (i - x, r - x): the path follows
       // the diagonal for as many steps as the leading lanes all find Diag inside this tile.
       const uint32_t ix = i - lane, rx = r - lane;
-      bool ok = lane < i && lane < r && rx - 1 >= s * STRIP;
+      bool ok = lane < i - lo && lane < r && rx - 1 >= s * STRIP;
       const uint32_t cx = ok ? rx - 1 : c;
       const uint32_t Lx = (cx % STRIP) / C, kx = cx % C, stx = (ok ? ix : i) + Lx - U0;
       ok = ok && stx >= tile_lo && Lx >= tile_lb;
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
         // the same lane's words.  A long gap in the query (a chain that spans far more reference than the
         // read is long) is walked 64 rows per iteration instead of one.  (Local: the score grows on the
         // way up, gap < 0, so no cell of the run is a zero cell.)
-        const bool okx = lane < i && st >= tile_lo + lane;
+        const bool okx = lane < i - lo && st >= tile_lo + lane;
         const uint32_t ux = okx ? Fmt::decode(tile[((st - lane - tile_lo) / SPW) * TW + (L - tile_lb)], c % C, half,
                                               (st - lane) % SPW)
                                 : (uint32_t)DIR_NONE;
@@ -701,13 +709,35 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   }
   if (cur_len) push_run((cur_len << 2) | cur_op);
   flush_runs();
-  if (lane != 0) return;
-  if (a.cigar_nruns) a.cigar_nruns[p] = nruns;
+  return WalkEnd{nruns, i, r, cur_op, cur_len, overflow};
+}
+
+// The first character pair of the CIGAR text decides what Global / Semiglobal report as target_begin: index 1
+// of the text is 'D' only for a leading D-run of 1..9 (src/alignment.cpp:244-246 reads the text).
+__device__ __forceinline__ uint32_t target_begin_of_first_run(uint32_t op, uint32_t len) {
+  return (len && op == SA_OP_D && len <= 9) ? 3u : 1u;
+}
+
+// One wavefront per pair walks the whole path.  a.tb_only (optional): only the pairs it marks.
+template <int MODE, class Fmt>
+__global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
+  const uint32_t pl = blockIdx.x;
+  if (pl >= a.pairs_in_pass) return;
+  if (a.tb_only && !a.tb_only[pl]) return;
+  const uint32_t p = a.pair_base + pl;
+  const uint32_t Q = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
+  const uint32_t T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
+  const uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
+  const uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
+  uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
+  const WalkEnd e = walk_wave<MODE, Fmt>(a, pl, i, r, 0, slot_end, ~0u);
+  if (threadIdx.x != 0) return;
+  if (a.cigar_nruns) a.cigar_nruns[p] = e.nruns;
   if (a.target_begin) {
     if (MODE == SA_LOCAL)
-      a.target_begin[p] = i;  // row where the traceback stopped (src/alignment.cpp:244-246)
-    else                      // index 1 of the CIGAR text is 'D' only for a leading D-run of 1..9
-      a.target_begin[p] = (cur_len && cur_op == SA_OP_D && cur_len <= 9) ? 3u : 1u;
+      a.target_begin[p] = e.i;  // row where the traceback stopped (src/alignment.cpp:244-246)
+    else
+      a.target_begin[p] = target_begin_of_first_run(e.last_op, e.last_len);
   }
 }
 

@@ -44,6 +44,10 @@ struct Options {
   std::atomic<long> pk16_k{48};       // SA_PK16_K: rows per strip of the packed lane kernel (32, 48, 64)
   std::atomic<long> min_chunk{0};     // SA_MIN_CHUNK: windows per minimizer chunk (0 automatic, 8..4096)
   std::atomic<long> no_buckets{0};    // SA_NO_BUCKETS: single sequences take the device-wide radix sort
+  std::atomic<long> no_segments{0};   // SA_NO_SEGMENTS: long pairs are traced back by one wavefront each
+  std::atomic<long> seg_rows{0};      // SA_SEG_ROWS: target rows per traceback segment (0 automatic)
+  std::atomic<long> seg_cap{0};       // SA_SEG_CAP: runs a traceback segment may hold (0: its share of the slot);
+                                      // a small value sends pairs to the one-wavefront walk (a test hook)
   std::atomic<long> fake_devices{0};  // SA_FAKE_DEVICES: the host batch calls deal to this many shards, all of
                                       // them on GPU 0 (exercises the multi-GPU path on one GPU)
 };

@@ -346,6 +346,73 @@ def test_cooperative_single_long_pair_vs_oracle(oracle):
         _run_group(cases)
 
 
+def _mutated(rng, t, sub, indel):
+    out = []
+    for c in t:
+        u = rng.random()
+        if u < indel / 2:
+            continue
+        if u < indel:
+            out.append(rng.choice("ACGT"))
+        out.append(c if rng.random() > sub else rng.choice("ACGT"))
+    return "".join(out) or "A"
+
+
+@pytest.mark.parametrize("cap", [0, 8])
+def test_segmented_traceback_vs_oracle(oracle, cap):
+    """The traceback of long Global / Semiglobal pairs by one wavefront per segment of target rows (speculative
+    starts, walked again from the column the segment above lands on, joined afterwards): with 64-row segments
+    pairs of a few hundred to a few thousand rows take that path.  Related pairs, unrelated ones (the walks meet
+    late or not at all inside a segment), two-letter alphabets (ties), long gaps inside the matrix and along its
+    borders, targets far longer than the query and the reverse, pairs of unequal length in one batch.  cap = 8:
+    every segment runs out of room for its runs, which sends the pair to the one-wavefront walk."""
+    from sequencealigner_amd import align, capi
+    rng = random.Random(2024 + cap)
+    batches = []
+    related = []
+    for _ in range(8):
+        T = rng.randint(600, 3000)
+        t = "".join(rng.choice("ACGT") for _ in range(T))
+        related.append((_mutated(rng, t, 0.05, 0.06), t))
+    batches.append(related)
+    batches.append([("".join(rng.choice("ACGT") for _ in range(rng.randint(500, 2200))),
+                     "".join(rng.choice("ACGT") for _ in range(rng.randint(700, 2200)))) for _ in range(6)])
+    batches.append([("".join(rng.choice("AC") for _ in range(rng.randint(500, 1500))),
+                     "".join(rng.choice("AC") for _ in range(rng.randint(700, 1500)))) for _ in range(6)])
+    gaps = []
+    for _ in range(4):
+        T = rng.randint(1500, 2600)
+        t = "".join(rng.choice("ACGT") for _ in range(T))
+        a, b = rng.randint(0, 200), rng.randint(T - 600, T - 300)
+        piece = rng.randint(150, 280)
+        q = _mutated(rng, t[a:a + piece] + t[b:b + piece], 0.03, 0.0)
+        gaps.append((q, t))
+        gaps.append((t, q))
+    gaps.append(("ACGTACGTAC", "T" * 700 + "ACGTACGTAC" + "G" * 900))
+    gaps.append(("T" * 700 + "ACGTACGTAC" + "G" * 900, "ACGTACGTAC" * 60))
+    batches.append(gaps)
+    _force_family("coop")
+    capi.set_option("seg_rows", 64)
+    capi.set_option("seg_cap", cap)
+    try:
+        n = 0
+        for pairs in batches:
+            for typ, (m, x, g) in ((0, (1, -1, -1)), (2, (1, -1, -1)), (0, (1, -3, -1)), (2, (2, -2, 0)),
+                                   (0, (1, 1, -1)), (2, (0, -1, -1))):
+                cases = _oracle_cases(oracle, pairs, typ, m, x, g)
+                if not cases:
+                    continue
+                b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
+                assert b.kernel_name() == "wave_i32_coop"
+                _run_group(cases)
+                n += len(cases)
+        assert n > 120
+    finally:
+        capi.set_option("seg_rows", 0)
+        capi.set_option("seg_cap", 0)
+        _force_family(None)
+
+
 def test_empty_and_odd_batches_vs_oracle(oracle, family):
     """Empty queries / targets next to ordinary pairs, and batches of 1 and 3 pairs (a packed wavefront or
     lane then holds a pair without a partner); the meaning of the empty cases is the one the CPU
