@@ -75,6 +75,7 @@ const char* sa_device_arch(int device);
  *                                      not by one wavefront per segment of target rows
  *   "seg_rows"      (SA_SEG_ROWS)      target rows per such segment, 0 automatic (1024, more for targets
  *                                      beyond 1 M rows)
+ *   "seg_spec"      (SA_SEG_SPEC)      walks a segment may make from columns that are not final yet (default 2)
  *   "seg_cap"       (SA_SEG_CAP)       runs a segment may hold, 0: its share of the pair's run slot; a small
  *                                      value sends pairs to the one-wavefront walk (a test hook)
  *   "fake_devices"  (SA_FAKE_DEVICES)  the host batch calls deal their units to this many shards, all run on

@@ -50,6 +50,7 @@ Options& options() {
     x->no_segments = num("SA_NO_SEGMENTS", 0);
     x->seg_rows = num("SA_SEG_ROWS", 0);
     x->seg_cap = num("SA_SEG_CAP", 0);
+    x->seg_spec = num("SA_SEG_SPEC", 2);
     x->fake_devices = num("SA_FAKE_DEVICES", 0);
     return x;
   }();
@@ -459,11 +460,15 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
         sg.nseg = nseg;
         sg.cap = (uint32_t)(a.cigar_stride / nseg);
         if (opt.seg_cap > 0 && (uint64_t)opt.seg_cap < sg.cap) sg.cap = (uint32_t)opt.seg_cap;
+        // generous: a segment along the straight line to the end cell has rows + rows * Q / T cells, at worst one
+        // or two per iteration; a guess that runs into the bound costs the segment that time once, not the pair
+        sg.spec_iters = (uint32_t)std::min<uint64_t>(2 * ((uint64_t)rows + (uint64_t)rows * a.max_q / a.max_t) + 64, 1u << 30);
         sg.pub = reinterpret_cast<uint64_t*>(a.brow);
         sg.seg_nruns = reinterpret_cast<uint32_t*>(sg.pub + (size_t)a.pairs_in_pass * nseg);
         sg.redo = sg.seg_nruns + (size_t)a.pairs_in_pass * nseg;
         sg.ticket = sg.redo + a.pairs_in_pass;
         sg.abort_flag = co.abort_flag;
+        sg.spec_walks = (uint32_t)std::max(0L, std::min(8L, (long)opt.seg_spec));
         hipLaunchKernelGGL(clear_words, dim3((unsigned)((state_words + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<uint32_t*>(a.brow), (uint32_t)state_words);
         hipLaunchKernelGGL((traceback_wave_segments<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass * nseg), dim3(64), 0,
@@ -551,7 +556,7 @@ int sa_set_option(const char* name, long value) {
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
-               {"seg_cap", &o.seg_cap}};
+               {"seg_cap", &o.seg_cap},     {"seg_spec", &o.seg_spec}};
   for (auto& e : table)
     if (!strcmp(name, e.name)) {
       *e.slot = value;

@@ -10,15 +10,17 @@
 // counts is therefore the number of instructions in ONE step and the lag, and this kernel is built around
 // those two:
 //   * narrow strips (C = 2 columns per lane while the strips of the batch still get a SIMD each): a step
-//     is 9 instructions per cell plus a fixed part, and the fixed part is kept to shifts between lanes -
-//     the target symbol of a row enters at lane 0 and moves up one lane per step (DPP), the left
-//     neighbour's value likewise, the values lane 63 hands to the next strip collect in a shift register
-//     that runs the other way; lane 0's inputs come out of a register with v_readlane at an unrolled,
-//     constant position.  No LDS, no address arithmetic, no branch inside a batch of 16 steps;
-//   * boundary rows are handed over in batches of 16 (published by lanes 47..62 out of the shift register) and
-//     fetched 32 at a time, one fetch ahead, by lanes 0..31 of the next strip: on gfx950 a wait for a load also
-//     waits for every store issued before it, so the kernel waits once per 32 steps.  A strip follows its
-//     neighbour at about 63 + 48 steps plus the memory latency;
+//     is 8 or 9 instructions per cell plus a fixed part, and the fixed part is four instructions: the lane's
+//     target symbol of the row comes out of an LDS ring of the last 128 rows (every row stored twice, 128 entries
+//     apart, so the 16 rows of a batch are contiguous from any start and each read is one instruction with a
+//     constant offset), lane 0's left value out of LDS too (all lanes read it, a one-lane DPP shift then gives
+//     every other lane the value of the lane below), and every lane drops its last column's value into LDS,
+//     where lanes 47..62 find lane 63's sixteen values after the batch.  Inputs are read one step ahead.  No
+//     address arithmetic and no branch inside a batch of 16 steps;
+//   * boundary rows are handed over in batches of 16 and fetched 32 at a time, one fetch ahead, by lanes
+//     0..31 of the next strip: on gfx950 a wait for a load also waits for every store issued before it, so the
+//     kernel waits once per 32 steps.  A strip follows its neighbour at about 63 + 48 steps plus the memory
+//     latency;
 //   * direction flags of 16 / C consecutive steps share one dword per lane (one store per 16 / C steps):
 //       dword[(s * ngroups + (st - 1) / SPW) * 64 + L],  SPW = 16 / C,  step st = i + L,
 //       step (st - 1) % SPW = x sits at bits [(SPW - 1 - x) * 2C, (SPW - x) * 2C), inside it cell k (column

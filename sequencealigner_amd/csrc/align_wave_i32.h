@@ -461,6 +461,7 @@ struct WaveFmtI32 {
 struct WalkEnd {
   uint32_t nruns, i, r, last_op, last_len;
   bool overflow;
+  bool gave_up;  // stopped after max_iters iterations, nowhere in particular
 };
 
 // Traceback + run-length encoding for the wavefront layouts by one wavefront (same rules as
@@ -468,10 +469,12 @@ struct WalkEnd {
 // block: the wave copies that block, the strip's query symbols and the target symbols of the rows it
 // spans into LDS and walks inside it; every lane follows the same path, the runs leave one per lane.
 // The walk starts at cell (i, r) and stops where the path ends or, with lo > 0, at the first cell of row lo
-// (no move is taken from that cell).  Runs are written backwards from slot_end, at most `cap` of them.
+// (no move is taken from that cell).  Runs are written backwards from slot_end, at most `cap` of them.  A walk
+// gives up after max_iters iterations (one iteration: a diagonal stretch plus a gap move, or up to 64 moves of
+// a gap run).
 template <int MODE, class Fmt>
 __device__ __forceinline__ WalkEnd walk_wave(const AlignArgs& a, uint32_t pl, uint32_t i, uint32_t r, uint32_t lo,
-                                             uint32_t* slot_end, uint32_t cap) {
+                                             uint32_t* slot_end, uint32_t cap, uint32_t max_iters) {
   using word_t = typename Fmt::word_t;
   constexpr int C = Fmt::C;
   constexpr uint32_t STRIP = 64 * C;
@@ -543,8 +546,13 @@ __device__ __forceinline__ WalkEnd walk_wave(const AlignArgs& a, uint32_t pl, ui
     const uint32_t v = x * 64 + lane, row = v / VPR, colv = v % VPR;
     return reinterpret_cast<const u32x4*>(dirs + ((uint64_t)s * nrows + lo / SPW + row) * 64 + lb) + colv;
   };
-  for (;;) {
+  bool gave_up = false;
+  for (uint32_t iters = 0;; ++iters) {
     if (lo && i <= lo) break;
+    if (iters >= max_iters) {
+      gave_up = true;
+      break;
+    }
     if (MODE == SA_GLOBAL && i == 0 && r == 0) break;
     if (MODE == SA_SEMIGLOBAL && r == 0) break;
     uint32_t d;
@@ -709,7 +717,7 @@ __device__ __forceinline__ WalkEnd walk_wave(const AlignArgs& a, uint32_t pl, ui
   }
   if (cur_len) push_run((cur_len << 2) | cur_op);
   flush_runs();
-  return WalkEnd{nruns, i, r, cur_op, cur_len, overflow};
+  return WalkEnd{nruns, i, r, cur_op, cur_len, overflow, gave_up};
 }
 
 // The first character pair of the CIGAR text decides what Global / Semiglobal report as target_begin: index 1
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   const uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
   const uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
-  const WalkEnd e = walk_wave<MODE, Fmt>(a, pl, i, r, 0, slot_end, ~0u);
+  const WalkEnd e = walk_wave<MODE, Fmt>(a, pl, i, r, 0, slot_end, ~0u, ~0u);
   if (threadIdx.x != 0) return;
   if (a.cigar_nruns) a.cigar_nruns[p] = e.nruns;
   if (a.target_begin) {

@@ -12,7 +12,11 @@
 //     segment whose upstream landing is final AND equal to the column it last started from marks its own
 //     landing final.  Finality moves down one segment per memory round trip, the walks themselves run in
 //     parallel, and whatever the guesses were, every segment ends up walking from the true path's column: the
-//     result is the path the single wavefront finds, run for run after `stitch_segments` has joined the parts.
+//     result is the path the single wavefront finds, run for run after `stitch_segments` has joined the parts;
+//   * speculation is bounded: a segment walks at most twice on speculative columns, and such a walk gives up
+//     after `spec_iters` iterations (a path with a gap of tens of thousands of columns is far from every guess,
+//     and walks that never meet it would queue up one behind the other).  A segment that has given up waits for
+//     the final column, so the worst case is the one wavefront's walk cut into pieces plus the bounded guesses.
 // A published landing is one 64-bit word {column, state}, written and read with single device-scope accesses.
 // Segments take their numbers from a ticket counter, topmost first, so a waiting wavefront waits only for
 // wavefronts that already run; every wait is bounded and raises the abort flag.  A segment whose runs outgrow
@@ -33,6 +37,8 @@ struct SegArgs {
   uint32_t rows;        // target rows per segment
   uint32_t nseg;        // segments per pair: ceil(max_t / rows), at most kMaxSegments
   uint32_t cap;         // runs a segment may write: cigar_stride / nseg
+  uint32_t spec_iters;  // iterations a speculative walk may take
+  uint32_t spec_walks;  // walks a segment may make on speculative columns
   uint64_t* pub;        // [pair of the pass][nseg]: landing of segment k = start of segment k - 1; zero at launch
   uint32_t* seg_nruns;  // [pair of the pass][nseg]; zero at launch
   uint32_t* redo;       // [pair of the pass]: nonzero = walk this pair with one wavefront instead; zero at launch
@@ -67,18 +73,20 @@ __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegAr
   const uint64_t* pub_in = pub_out + 1;  // read only when k < ktop
 
   uint32_t land = 0, nruns = 0;
-  bool overflow = false;
-  auto walk = [&](uint32_t col) __attribute__((always_inline)) {
+  bool overflow = false, gave_up = false;
+  auto walk = [&](uint32_t col, uint32_t max_iters) __attribute__((always_inline)) {
+    gave_up = false;
     if (col == kSegEnded) {
       land = kSegEnded;
       nruns = 0;
       overflow = false;
       return;
     }
-    const WalkEnd e = walk_wave<MODE, Fmt>(a, pl, hi, col, lo, part_end, sg.cap);
+    const WalkEnd e = walk_wave<MODE, Fmt>(a, pl, hi, col, lo, part_end, sg.cap, max_iters);
     land = (lo && e.i > lo) ? kSegEnded : e.r;  // stopped above row lo: the path ended there
     nruns = e.nruns;
     overflow = e.overflow;
+    gave_up = e.gave_up;
   };
   auto publish = [&](uint32_t state) __attribute__((always_inline)) {
     if (k && lane == 0)
@@ -100,19 +108,21 @@ __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegAr
   uint32_t next_col = Q, next_state = SEG_FINAL;  // the topmost segment starts at the end cell
   bool pending = true;
   if (k < ktop) {
-    pending = (uint32_t)(upstream() >> 32) == SEG_NONE;
+    pending = sg.spec_walks && (uint32_t)(upstream() >> 32) == SEG_NONE;
     if (pending) {  // nothing known yet: the straight line to the end cell
       next_col = (uint32_t)((uint64_t)hi * Q / i_end);
       next_state = SEG_SPECULATIVE;
     }
   }
-  bool walked = false;
+  bool walked = false;        // `land` and the runs are those of a finished walk from column `used`
   uint32_t used = 0;
+  uint32_t spec_left = sg.spec_walks;  // walks this segment may still make on speculative columns
   for (uint32_t polls = 0;;) {
     if (!pending) {
       const uint64_t u = upstream();
       const uint32_t state = (uint32_t)(u >> 32), col = (uint32_t)u;
-      if (state == SEG_NONE || (walked && col == used && state != SEG_FINAL)) {  // nothing new
+      const bool fresh = state == SEG_FINAL || (state == SEG_SPECULATIVE && spec_left && !(walked && col == used));
+      if (!fresh) {
         __builtin_amdgcn_s_sleep(2);
         if (++polls >= kSpinLimit ||
             ((polls & 1023u) == 1023u && __hip_atomic_load(sg.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -126,11 +136,13 @@ __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegAr
     }
     pending = false;
     if (!walked || next_col != used) {
-      walk(next_col);
+      const bool final_col = next_state == SEG_FINAL;
+      if (!final_col) --spec_left;
+      walk(next_col, final_col ? ~0u : sg.spec_iters);
       used = next_col;
-      walked = true;
+      walked = !gave_up;
     }
-    publish(next_state);
+    if (walked) publish(next_state);
     if (next_state == SEG_FINAL) break;
   }
   finish();
