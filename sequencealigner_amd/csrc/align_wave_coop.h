@@ -190,20 +190,16 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
 
   // One step at position X of its batch.  FULL: every lane has a valid row, nothing is predicated.
   // TRACK: Semiglobal's last strip, which follows the last column's maximum row by row.
-  // tp: the lane's target rows of this batch, bp: lane 0's left values of the batch; tc / bl arrive one step ahead.
-  auto step = [&](uint32_t b0, auto x_tag, auto full_tag, auto track_tag, const int* tp, const int* bp, int& tc_next,
-                  int& bl_next) __attribute__((always_inline)) {
+  // tcv: the lane's target rows of this batch, blv: lane 0's left values of the batch.
+  auto step = [&](uint32_t b0, auto x_tag, auto full_tag, auto track_tag, const int (&tcv)[B], const int (&blv)[B])
+                  __attribute__((always_inline)) {
     constexpr uint32_t X = decltype(x_tag)::value;
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr bool TRACK = decltype(track_tag)::value;
     const uint32_t st = b0 + X;
-    const int tc = tc_next;
+    const int tc = tcv[X];
     // lane 0 takes the boundary value, every other lane the value of the lane below
-    const int recv = dpp_shr1(bl_next, lastcol);
-    if (X + 1 < B) {
-      tc_next = tp[X + 1];
-      bl_next = bp[X + 1];
-    }
+    const int recv = dpp_shr1(blv[X], lastcol);
     uint32_t bits = FULL ? acc : 0u;
     const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
     if (FULL || (st > lane && i <= T)) {
@@ -249,8 +245,13 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
   auto batch = [&](uint32_t b0, uint32_t half, auto full_tag, auto track_tag) __attribute__((always_inline)) {
     const int* tp = trows + ((b0 - lane) % kCoopRing);
     const int* bp = bleft + ((((b0 - 1) / kCoopFetch) & 1u) * kCoopFetch + half * B);
-    int tc_next = tp[0], bl_next = bp[0];
-#define SA_COOP_STEP(X) step(b0, std::integral_constant<uint32_t, X>{}, full_tag, track_tag, tp, bp, tc_next, bl_next);
+    int tcv[B], blv[B];  // the batch's inputs, read in one go: no step waits for LDS
+#pragma unroll
+    for (uint32_t x = 0; x < B; ++x) {
+      tcv[x] = tp[x];
+      blv[x] = bp[x];
+    }
+#define SA_COOP_STEP(X) step(b0, std::integral_constant<uint32_t, X>{}, full_tag, track_tag, tcv, blv);
     SA_COOP_STEP(0) SA_COOP_STEP(1) SA_COOP_STEP(2) SA_COOP_STEP(3) SA_COOP_STEP(4) SA_COOP_STEP(5)
     SA_COOP_STEP(6) SA_COOP_STEP(7) SA_COOP_STEP(8) SA_COOP_STEP(9) SA_COOP_STEP(10) SA_COOP_STEP(11)
     SA_COOP_STEP(12) SA_COOP_STEP(13) SA_COOP_STEP(14) SA_COOP_STEP(15)
