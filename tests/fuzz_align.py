@@ -40,6 +40,12 @@ def main():
         capi.set_option("force_i32", 1 if fam == "wave32" else 0)
         capi.set_option("force_family", {None: 0, "lane": 1}.get(fam, 2))
         capi.set_option("force_coop", 1 if fam == "coop" else 0 if fam in ("wave", "wave32") else -1)
+        # the cooperative family: half of the batches with 64-row traceback segments (pairs of a few hundred rows
+        # then take the many-wavefront traceback), with 0..3 speculative walks and sometimes no room for the runs
+        short_segments = fam == "coop" and rng.random() < 0.5
+        capi.set_option("seg_rows", 64 if short_segments else 0)
+        capi.set_option("seg_spec", rng.choice([0, 1, 2, 2, 3]) if short_segments else 2)
+        capi.set_option("seg_cap", 8 if short_segments and rng.random() < 0.2 else 0)
         typ = rng.choice([0, 1, 2])
         match, mismatch, gap = rng.choice([0, 1, 1, 2, 3]), rng.choice([-3, -2, -1, -1, 0, 1]), rng.choice([-3, -2, -1, -1, 0, 1])
         big = rng.random() < 0.15
