@@ -106,7 +106,9 @@ int sa_set_option(const char* name, long value);
  *   d_cigar_runs       n * cigar_stride uint32 run slots; pair p owns slots [p*stride, (p+1)*stride) and
  *                      its runs, in forward (CIGAR text) order, end at the end of its slot range:
  *                      first run at p*stride + stride - d_cigar_nruns[p].  Needs
- *                      cigar_stride >= max_qlen + max_tlen (a run per op in the worst case).
+ *                      cigar_stride >= max_qlen + max_tlen (a run per op in the worst case).  The slots
+ *                      before a pair's first run hold nothing the caller may rely on (the traceback of long
+ *                      pairs assembles the runs there).
  *   d_cigar_nruns[p]   number of runs
  * ------------------------------------------------------------------------------------------- */
 typedef struct sa_align_batch {
