@@ -288,17 +288,33 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
   if (!poll_entries(1, e_cur)) return false;
   stage_rows(1, row_words(t_cur), (int)(uint32_t)e_cur);
   // up to one batch beyond the last step, in which the last rows of the boundary are handed over
+#ifdef SA_COOP_TIMERS  // a build for tools/coopbench.py: where a strip's time goes (100 MHz ticks)
+  const uint64_t tm_start = wall_clock64();
+  uint64_t tm_batches = 0, tm_wait = 0;
+#define SA_TM(var, code)                     \
+  {                                          \
+    const uint64_t tm0 = wall_clock64();     \
+    code;                                    \
+    var += wall_clock64() - tm0;             \
+  }
+#else
+#define SA_TM(var, code) code;
+#endif
   for (uint32_t b0 = 1; b0 <= steps + B; b0 += kCoopFetch) {
     // fetch the inputs of the next two batches now, look at them after this pair of batches
     uint64_t e_next = load_entries(b0 + kCoopFetch);
     const int t_next = load_syms(b0 + kCoopFetch);
-    run_batch(b0, 0);
-    publish(b0);
-    run_batch(b0 + B, 1);
-    publish(b0 + B);
-    if (!poll_entries(b0 + kCoopFetch, e_next)) return false;
+    SA_TM(tm_batches, run_batch(b0, 0); publish(b0); run_batch(b0 + B, 1); publish(b0 + B))
+    SA_TM(tm_wait, if (!poll_entries(b0 + kCoopFetch, e_next)) return false)
     stage_rows(b0 + kCoopFetch, row_words(t_next), (int)(uint32_t)e_next);
   }
+#undef SA_TM
+#ifdef SA_COOP_TIMERS
+  if (lane == 0 && (s < 3 || s % 100 == 0 || last_strip))
+    printf("strip %u: started %.1f us after the launch's first tick, ran %.1f us: batches %.1f us, waits %.1f us\n", s,
+           (double)(tm_start % 100000000ull) / 100.0, (double)(wall_clock64() - tm_start) / 100.0,
+           (double)tm_batches / 100.0, (double)tm_wait / 100.0);
+#endif
   {  // Global: a lane's registers keep the values of its last row, H[T][column] + gap
     uint32_t pick = 0;
 #pragma unroll
