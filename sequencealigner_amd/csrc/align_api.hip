@@ -191,10 +191,21 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
       // wavefronts of the batch stay resident, else 8; the option "coop_c" = 4 | 8 pins it
       coop_c = coop_opt == 4 || coop_opt == 8 ? (int)coop_opt : ((uint64_t)b.n * ((max_q + 255) / 256) <= 2048 ? 4 : 8);
     } else {
-      // Global / Semiglobal: the narrowest strips (2, 4 or 8 columns per lane) that still give every strip of
-      // the batch a SIMD of its own - a single pair is bound by the length of one step, see align_wave_coop.h
-      for (int c : {2, 4, 8})
-        if (!coop_c && (uint64_t)b.n * ((max_q + 64 * c - 1) / (64 * c)) <= 1024) coop_c = c;
+      // Global / Semiglobal: 2, 4 or 8 columns per lane, among the widths that still give every strip of the
+      // batch a SIMD of its own.  A pair takes (target rows x time of a step) + (strips x time between the
+      // starts of neighbouring strips), see align_wave_coop.h; both times grow with the width (measured on
+      // MI355X: 68 / 95 / 155 ns and 8.8 / 11.6 / 17.1 us), the number of strips falls with it.
+      double best_time = 0;
+      for (int c : {2, 4, 8}) {
+        const uint64_t strips = (max_q + 64 * c - 1) / (64 * c);
+        if ((uint64_t)b.n * strips > 1024) continue;
+        const double step_ns = c == 2 ? 68 : c == 4 ? 95 : 155, between_ns = c == 2 ? 8800 : c == 4 ? 11600 : 17100;
+        const double time = max_t * step_ns + strips * between_ns;
+        if (!coop_c || time < best_time) {
+          coop_c = c;
+          best_time = time;
+        }
+      }
       if (!coop_c) coop_c = 8;
       if (coop_opt == 2 || coop_opt == 4 || coop_opt == 8) coop_c = (int)coop_opt;
     }
