@@ -67,6 +67,8 @@ const char* sa_device_arch(int device);
  *   "force_coop"    (SA_FORCE_COOP)    -1 automatic, 0 / 1: cooperative wavefront kernel off / on where possible
  *   "no_tables"     (SA_NO_TABLES)     1: no kernel looks substitution scores up in tables
  *   "coop_c"        (SA_COOP_C)        columns per lane of the cooperative kernel, 0 automatic
+ *   "coop_waves"    (SA_COOP_WAVES)    wavefronts (strips of pairs) in one pass of the cooperative Global / Semiglobal
+ *                                      kernel, 64..8192 (default 8192)
  *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64
  *   "min_chunk"     (SA_MIN_CHUNK)     windows per minimizer chunk, 0 automatic
  *   "no_buckets"    (SA_NO_BUCKETS)    1: a single sequence is sorted by the device-wide radix sort, as sequences

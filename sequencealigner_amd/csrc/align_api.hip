@@ -44,6 +44,7 @@ Options& options() {
     x->force_coop = num("SA_FORCE_COOP", -1);
     x->no_tables = getenv("SA_NO_TABLES") != nullptr;
     x->coop_c = num("SA_COOP_C", 0);
+    x->coop_waves = num("SA_COOP_WAVES", 8192);
     x->pk16_k = num("SA_PK16_K", 48);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
@@ -184,7 +185,12 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
     // the batch stay resident, else 8; SA_COOP_C=4|8 pins it
     const long coop_opt = opt.coop_c;
     const long force_coop = opt.force_coop;
-    const bool coop_wanted = allow_coop && (force_coop >= 0 ? force_coop != 0 : (b.n <= 256 && max_q > 1024));
+    // Measured on MI355X (tools/cooppass.py): the one-wavefront-per-pair kernels need about a thousand wavefronts
+    // before they use the GPU (256 pairs of 10 kbp x 11 kbp: 48 ms, as long as 2048 pairs), the cooperative
+    // Global / Semiglobal kernel, run in passes of up to 8192 wavefronts, fills at 2.3 TCUPS whatever the number
+    // of pairs (256 pairs: 12 ms, 1024: 45 ms, 2048: 91 ms; 64 pairs of 30 kbp x 33 kbp 27 against 316 ms).
+    const uint64_t coop_pairs = b.type == SA_LOCAL ? 256 : 768;
+    const bool coop_wanted = allow_coop && (force_coop >= 0 ? force_coop != 0 : (b.n <= coop_pairs && max_q > 1024));
     int coop_c = 0;
     if (b.type == SA_LOCAL) {
       // columns per lane of the cooperative Local kernel: 4 (more, shorter steps in flight) while all
@@ -210,7 +216,10 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
       if (coop_opt == 2 || coop_opt == 4 || coop_opt == 8) coop_c = (int)coop_opt;
     }
     const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
-    pl.coop = coop_wanted && b.n * strips8 <= 2048;
+    // Local: all strips of the batch in one pass; Global / Semiglobal: passes of as many pairs as the limit on
+    // resident wavefronts allows, at least one
+    const uint64_t coop_waves = (uint64_t)std::max(64L, std::min(8192L, (long)opt.coop_waves));
+    pl.coop = coop_wanted && (b.type == SA_LOCAL ? b.n * strips8 <= 2048 : strips8 <= coop_waves);
     // A small batch of short queries is bound by the time of one step, not by throughput: 4 or 8 columns
     // per lane instead of 16 put more lanes of the wavefront to work and shorten the step.
     const bool narrow = !pl.coop && max_q <= 512 && b.n <= 4096;
@@ -564,7 +573,8 @@ int sa_set_option(const char* name, long value) {
     const char* name;
     std::atomic<long>* slot;
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
-               {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"pk16_k", &o.pk16_k},
+               {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"coop_waves", &o.coop_waves},
+               {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
                {"seg_cap", &o.seg_cap},     {"seg_spec", &o.seg_spec}};
@@ -785,8 +795,10 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     co.abort_flag = (int*)d_workspace + 1;
     co.cand = (int32_t*)w;
     SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
-    // all waves of a pass must be resident at once
-    const size_t cap = std::max<size_t>(1, 2048 / pl.nstrips);
+    // Wavefronts of one pass.  They need not all be resident: strips take their numbers from a ticket counter in
+    // start order, so a strip only ever waits for strips that already run (Local: one pass, all resident).
+    const size_t coop_waves = b->type == SA_LOCAL ? 2048 : (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
+    const size_t cap = std::max<size_t>(1, coop_waves / pl.nstrips);
     if (pairs_per_pass > cap) pairs_per_pass = cap;
   }
   a.nstrips = pl.nstrips;

@@ -40,6 +40,8 @@ struct Options {
   std::atomic<long> force_family{0};  // SA_FORCE_FAMILY: 0 automatic, 1 lane kernels, 2 wavefront kernels
   std::atomic<long> force_coop{-1};   // SA_FORCE_COOP: -1 automatic, 0 / 1 pin the cooperative wavefront kernel
   std::atomic<long> no_tables{0};     // SA_NO_TABLES: packed lane kernel without the score-table form
+  std::atomic<long> coop_waves{8192}; // SA_COOP_WAVES: wavefronts of one pass of the cooperative Global /
+                                      // Semiglobal kernel (64..8192)
   std::atomic<long> coop_c{0};        // SA_COOP_C: columns per lane of the cooperative kernel (0 automatic)
   std::atomic<long> pk16_k{48};       // SA_PK16_K: rows per strip of the packed lane kernel (32, 48, 64)
   std::atomic<long> min_chunk{0};     // SA_MIN_CHUNK: windows per minimizer chunk (0 automatic, 8..4096)

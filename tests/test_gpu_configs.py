@@ -75,10 +75,15 @@ def test_config3_semiglobal_10k_x_11k_packed_wavefront_kernel(oracle):
     n = 512
     q, t = synth.pairs_semiglobal_long(n, seed=3)
     assert q.shape == (n, 10_000) and t.shape == (n, 11_000)
-    b = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
-    assert b.kernel_name() == "wave_pk16"
-    b.run()
-    torch.cuda.synchronize()
+    from sequencealigner_amd import capi
+    capi.set_option("force_coop", 0)   # (512 pairs alone would take the cooperative kernel, see below)
+    try:
+        b = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
+        assert b.kernel_name() == "wave_pk16"
+        b.run()
+        torch.cuda.synchronize()
+    finally:
+        capi.set_option("force_coop", -1)
     scores = b.scores()
     qb, qo = synth.to_blob(q)
     tb, to = synth.to_blob(t)
@@ -94,9 +99,21 @@ def test_config3_semiglobal_10k_x_11k_packed_wavefront_kernel(oracle):
     for i in range(3):
         want = oracle.align(bytes(q[i]), bytes(t[i]), 2, 1, -1, -1)
         assert (int(scores[i]), cig[i], 1) == want, i
+    # Left to the dispatcher, 512 long pairs are too few wavefronts for the one-pair-per-wavefront kernels: they
+    # run on the cooperative kernel in passes, with the traceback in segments, and give the same runs.
+    bc = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
+    assert bc.kernel_name() == "wave_i32_coop"
+    bc.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(bc.scores(), scores) and np.array_equal(bc.target_begins(), b.target_begins())
+    nruns_c = bc.d_nruns[:n].cpu().numpy()
+    assert np.array_equal(nruns_c, nruns)
+    runs_c = bc.d_runs.cpu().numpy().view(np.uint32).reshape(n, bc.stride)
+    for i in range(n):
+        assert np.array_equal(runs_c[i, bc.stride - nruns[i]:], runs[i, b.stride - nruns[i]:]), i
+    del bc, runs_c
     # the same 3 pairs as a batch of their own, pinned to the packed kernel (so few pairs would otherwise run
     # on the cooperative kernel)
-    from sequencealigner_amd import capi
     capi.set_option("force_coop", 0)
     try:
         b3 = align.DeviceAlignBatch(q[:3], t[:3], 2, 1, -1, -1)
