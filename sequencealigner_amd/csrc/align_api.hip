@@ -189,7 +189,8 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
     // before they use the GPU (256 pairs of 10 kbp x 11 kbp: 48 ms, as long as 2048 pairs), the cooperative
     // Global / Semiglobal kernel, run in passes of up to 8192 wavefronts, fills at 2.3 TCUPS whatever the number
     // of pairs (256 pairs: 12 ms, 1024: 45 ms, 2048: 91 ms; 64 pairs of 30 kbp x 33 kbp 27 against 316 ms).
-    const uint64_t coop_pairs = b.type == SA_LOCAL ? 256 : 768;
+    // (the cooperative Local kernel, an older design: 256 pairs of 10 kbp 16 against 47 ms, 512 pairs 34 against 47)
+    const uint64_t coop_pairs = b.type == SA_LOCAL ? 512 : 768;
     const bool coop_wanted = allow_coop && (force_coop >= 0 ? force_coop != 0 : (b.n <= coop_pairs && max_q > 1024));
     int coop_c = 0;
     if (b.type == SA_LOCAL) {
@@ -216,10 +217,9 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
       if (coop_opt == 2 || coop_opt == 4 || coop_opt == 8) coop_c = (int)coop_opt;
     }
     const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
-    // Local: all strips of the batch in one pass; Global / Semiglobal: passes of as many pairs as the limit on
-    // resident wavefronts allows, at least one
+    // passes of as many pairs as the limit on a pass's wavefronts allows, at least one
     const uint64_t coop_waves = (uint64_t)std::max(64L, std::min(8192L, (long)opt.coop_waves));
-    pl.coop = coop_wanted && (b.type == SA_LOCAL ? b.n * strips8 <= 2048 : strips8 <= coop_waves);
+    pl.coop = coop_wanted && strips8 <= coop_waves;
     // A small batch of short queries is bound by the time of one step, not by throughput: 4 or 8 columns
     // per lane instead of 16 put more lanes of the wavefront to work and shorten the step.
     const bool narrow = !pl.coop && max_q <= 512 && b.n <= 4096;
@@ -797,7 +797,7 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
     // Wavefronts of one pass.  They need not all be resident: strips take their numbers from a ticket counter in
     // start order, so a strip only ever waits for strips that already run (Local: one pass, all resident).
-    const size_t coop_waves = b->type == SA_LOCAL ? 2048 : (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
+    const size_t coop_waves = (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
     const size_t cap = std::max<size_t>(1, coop_waves / pl.nstrips);
     if (pairs_per_pass > cap) pairs_per_pass = cap;
   }

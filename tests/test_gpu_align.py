@@ -323,15 +323,23 @@ def test_local_ties_across_strips_vs_oracle(oracle):
         qb, qo = synth.to_blob(qs)
         tb_, to = synth.to_blob(ts)
         for (m, x, g) in ((1, -1, -1), (1, -3, -3), (2, -1, -2)):
-            b = align.DeviceAlignBatch(qs, ts, 1, m, x, g)
-            assert b.kernel_name() == ("wave_pk16" if hi == 1900 and m == 1 else "wave_i32")
-            b.run()
-            torch.cuda.synchronize()
-            s, tbeg = oracle.align_batch(qb, qo, tb_, to, 1, m, x, g, True, 16)
-            assert np.array_equal(b.scores(), s)
-            assert np.array_equal(b.target_begins(), tbeg)      # the start row depends on the end cell chosen
-            for i in range(0, n, 29):
-                assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), 1, m, x, g)[1]
+            # one wavefront per pair (pinned), then the dispatcher's choice for 300 long pairs: the cooperative
+            # kernel in passes, whose strips' candidates are merged by the same rule
+            for fam, want_kernel in (("wave", "wave_pk16" if hi == 1900 and m == 1 else "wave_i32"),
+                                     (None, "wave_i32_coop")):
+                _force_family(fam)
+                try:
+                    b = align.DeviceAlignBatch(qs, ts, 1, m, x, g)
+                    assert b.kernel_name() == want_kernel
+                    b.run()
+                    torch.cuda.synchronize()
+                finally:
+                    _force_family(None)
+                s, tbeg = oracle.align_batch(qb, qo, tb_, to, 1, m, x, g, True, 16)
+                assert np.array_equal(b.scores(), s)
+                assert np.array_equal(b.target_begins(), tbeg)      # the start row depends on the end cell chosen
+                for i in range(0, n, 29):
+                    assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), 1, m, x, g)[1]
 
 
 def test_cooperative_single_long_pair_vs_oracle(oracle):
