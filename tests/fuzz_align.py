@@ -46,6 +46,8 @@ def main():
         capi.set_option("seg_rows", 64 if short_segments else 0)
         capi.set_option("seg_spec", rng.choice([0, 1, 2, 2, 3]) if short_segments else 2)
         capi.set_option("seg_cap", 8 if short_segments and rng.random() < 0.2 else 0)
+        # and with few wavefronts per pass, so that a batch takes several passes
+        capi.set_option("coop_waves", rng.choice([64, 256, 8192]) if fam == "coop" else 8192)
         typ = rng.choice([0, 1, 2])
         match, mismatch, gap = rng.choice([0, 1, 1, 2, 3]), rng.choice([-3, -2, -1, -1, 0, 1]), rng.choice([-3, -2, -1, -1, 0, 1])
         big = rng.random() < 0.15
