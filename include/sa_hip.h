@@ -94,8 +94,9 @@ int sa_set_option(const char* name, long value);
  * d_t[t_off[p] .. t_off[p+1]).  All d_* pointers are device pointers on `device`; `stream` is a
  * hipStream_t (NULL = default stream).  d_q and d_t must be readable up to 8 bytes past their last
  * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except for
- * batches of few long pairs, which run cooperatively (kernel name "wave_i32_coop") and synchronise the
- * stream once at the end to read the kernels' abort flag.
+ * batches of few pairs (hundreds, not thousands) of more than a few hundred symbols, which run cooperatively
+ * (kernel name "wave_i32_coop", see sa_align_kernel_name) and synchronise the stream once at the end to read
+ * the kernels' abort flag; sa_align_batch_device_static never does.
  *
  * The batch is planned for max_qlen x max_tlen: every pair pays for direction words and steps of that shape.
  * Callers with mixed sizes should issue one call per size class (sa_align_batch_host does).

@@ -46,10 +46,17 @@ def test_static_scratch_entry_point_equals_workspace_entry_point(oracle):
         assert np.array_equal(w, g)
     for i in range(0, 16_000, 1601):   # and the workspace path is itself checked against the CPU checker
         assert (int(want[0][i]), big.cigars([i])[0], int(want[1][i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
-    # call 2, right after it on the same array, smaller: 60 Global pairs on the packed wavefront kernel
+    # call 2, right after it on the same array, smaller: 60 Global pairs.  The workspace entry point runs so few
+    # pairs on the cooperative kernel, the static-scratch one never does (it only enqueues work) and takes the
+    # packed wavefront kernel: two different kernels must agree
     q2, t2 = synth.pairs_global_1k(60, seed=32, length=700)
     small = align.DeviceAlignBatch(q2, t2[:, :650], 0, 1, -1, -1)
-    assert small.kernel_name() == "wave_pk16"
+    assert small.kernel_name() == "wave_i32_coop"
+    capi.set_option("force_coop", 0)
+    try:
+        assert small.kernel_name() == "wave_pk16"
+    finally:
+        capi.set_option("force_coop", -1)
     want, got = _both_ways(small)
     for w, g in zip(want, got):
         assert np.array_equal(w, g)

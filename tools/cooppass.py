@@ -30,7 +30,8 @@ def run(q, t, typ, label):
     return s
 
 
-shapes = [(10_000, 11_000, (128, 256, 512, 1024, 2048)), (3_000, 3_300, (256, 1024, 4096)), (30_000, 33_000, (64, 256))]
+shapes = [(10_000, 11_000, (128, 256, 512, 1024, 2048)), (3_000, 3_300, (256, 1024, 4096)), (30_000, 33_000, (64, 256)),
+          (800, 50_000, (16, 100, 400)), (1000, 1100, (16, 100, 400, 1000)), (500, 5000, (100, 400))]
 for read_len, window_len, counts in shapes:
     for n in counts:
         q, t = synth.pairs_semiglobal_long(n, seed=3, read_len=read_len, window_len=window_len, lead=200)
@@ -39,8 +40,8 @@ for read_len, window_len, counts in shapes:
         capi.set_option("force_coop", 0)
         ref = run(q, t, 2, "one wavefront per pair")
         capi.set_option("force_coop", 1)
-        for c in (4, 8):
-            for waves in (1024, 2048, 4096, 8192):
+        for c in (2, 4, 8):
+            for waves in ((1024, 2048, 4096, 8192) if read_len >= 3000 else (8192,)):
                 capi.set_option("coop_c", c)
                 capi.set_option("coop_waves", waves)
                 s = run(q, t, 2, f"cooperative C {c} waves/pass {waves}")
