@@ -193,7 +193,9 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
     const uint64_t coop_pairs = b.type == SA_LOCAL ? 512 : 768;
     // Queries of a few hundred columns gain as well while the pairs are few (tools/cooppass.py: 100 pairs of
     // 800 x 50 000 3.7 against 24 ms, 100 pairs of 1000 x 1100 0.18 against 0.58 ms, 400 pairs 0.26 against 0.58).
-    const uint32_t coop_min_q = b.type == SA_LOCAL ? 1024 : 256;
+    // (Local, the older cooperative kernel: 100 pairs of 1000 x 1100 0.32 against 0.69 ms, of 800 x 50 000 9.3
+    // against 28.8 ms)
+    const uint32_t coop_min_q = 256;
     const bool coop_wanted =
         allow_coop && (force_coop >= 0 ? force_coop != 0 : (b.n <= coop_pairs && max_q > coop_min_q));
     int coop_c = 0;
