@@ -754,6 +754,25 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
   const size_t units_per_pass = blocks_per_pass * pl.units_per_block;
   size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 
+  // One wavefront per pair in several passes: the pairs left over for the last pass are a batch of their own,
+  // planned anew - a few hundred of them are too few wavefronts for these kernels (424 pairs of 10 kbp x 11 kbp
+  // take as long as 2048) and run on the cooperative kernel instead.
+  if (pl.family == Family::WaveI32 && !pl.coop && !static_scratch_call && b->n > pairs_per_pass &&
+      b->n % pairs_per_pass != 0 && b->n % pairs_per_pass <= 768) {
+    const size_t rest_n = b->n % pairs_per_pass, head_n = b->n - rest_n;
+    sa_align_batch head = *b, rest = *b;
+    head.n = (uint32_t)head_n;
+    rest.n = (uint32_t)rest_n;
+    rest.d_q_off += head_n;
+    rest.d_t_off += head_n;
+    rest.d_score += head_n;
+    if (rest.d_target_begin) rest.d_target_begin += head_n;
+    if (rest.d_cigar_runs) rest.d_cigar_runs += head_n * b->cigar_stride;
+    if (rest.d_cigar_nruns) rest.d_cigar_nruns += head_n;
+    if (int rc = align_batch_device(device, stream_, &head, d_workspace, workspace_bytes, false)) return rc;
+    return align_batch_device(device, stream_, &rest, d_workspace, workspace_bytes, false);
+  }
+
   // carve the workspace
   static_assert(sizeof(AlphabetInfo) <= kFixedWorkspace, "fixed workspace too small");
   AlphabetInfo* alpha = nullptr;

@@ -150,6 +150,40 @@ def test_small_workspace_multiple_passes(oracle):
         assert (int(s[i]), cg[i], int(tb[i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
 
 
+def test_leftover_pairs_of_the_last_pass(oracle):
+    """900 pairs of 1.1 kbp on the packed wavefront kernel with a workspace for 256 pairs per pass: the 132 pairs
+    left over for the last pass are planned as a batch of their own (the cooperative kernel: they are too few
+    wavefronts for one wavefront per pair), through offsets into the same arrays.  With the cooperative kernel
+    switched off they run as a fourth pass of the packed kernel.  Every pair against the CPU checker."""
+    import ctypes as C
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    n = 900
+    q, t = synth.pairs_semiglobal_long(n, seed=12, read_len=1100, window_len=1200, lead=40)
+    qb, qo = synth.to_blob(q)
+    tb_, to = synth.to_blob(t)
+    for typ in (2, 0):
+        want_s, want_tb = oracle.align_batch(qb, qo, tb_, to, typ, 1, -1, -1, True, 16)
+        for coop in (-1, 0):
+            capi.set_option("force_coop", coop)
+            try:
+                probe = align.DeviceAlignBatch(q, t, typ, 1, -1, -1)
+                assert probe.kernel_name() == "wave_pk16"
+                mn = C.c_size_t(0)
+                capi.lib().sa_align_workspace_bytes(C.byref(probe.batch), C.byref(mn))
+                per_block = mn.value - 1024          # the minimum is one block of two pairs plus the fixed head
+                del probe
+                b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1, workspace_bytes=1024 + 128 * per_block)
+                b.run()
+                torch.cuda.synchronize()
+            finally:
+                capi.set_option("force_coop", -1)
+            assert np.array_equal(b.scores(), want_s) and np.array_equal(b.target_begins(), want_tb)
+            cg = b.cigars(list(range(0, n, 37)) + list(range(760, n, 9)))
+            for k, i in enumerate(list(range(0, n, 37)) + list(range(760, n, 9))):
+                assert cg[k] == oracle.align(bytes(q[i]), bytes(t[i]), typ, 1, -1, -1)[1], (typ, coop, i)
+
+
 def test_more_pairs_than_one_launch_holds(oracle):
     """4.5 million tiny pairs: the batch exceeds what one pass may launch (2^22 pairs) although the
     workspace would hold it, so the passes are cut by the launch limits."""
