@@ -200,9 +200,10 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
         allow_coop && (force_coop >= 0 ? force_coop != 0 : (b.n <= coop_pairs && max_q > coop_min_q));
     int coop_c = 0;
     if (b.type == SA_LOCAL) {
-      // columns per lane of the cooperative Local kernel: 4 (more, shorter steps in flight) while all
-      // wavefronts of the batch stay resident, else 8; the option "coop_c" = 4 | 8 pins it
-      coop_c = coop_opt == 4 || coop_opt == 8 ? (int)coop_opt : ((uint64_t)b.n * ((max_q + 255) / 256) <= 2048 ? 4 : 8);
+      // columns per lane of the cooperative Local kernel: 4 (more, shorter steps in flight) while every strip of
+      // the batch gets a SIMD of its own, else 8 (400 pairs of 1000 x 1100: 0.41 against 0.48 ms); the option
+      // "coop_c" = 4 | 8 pins it
+      coop_c = coop_opt == 4 || coop_opt == 8 ? (int)coop_opt : ((uint64_t)b.n * ((max_q + 255) / 256) <= 1024 ? 4 : 8);
     } else {
       // Global / Semiglobal: 2, 4 or 8 columns per lane, among the widths that still give every strip of the
       // batch a SIMD of its own.  A pair takes (target rows x time of a step) + (strips x time between the
@@ -471,11 +472,12 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
       // Long pairs: the path is walked by one wavefront per segment of target rows (align_wave_segments.h), the
       // state of the segments in the boundary area, which the fill has finished with.
       const Options& opt = options();
-      uint32_t rows = opt.seg_rows > 0 ? (uint32_t)round_up((size_t)opt.seg_rows, 64) : 1024;
+      // rows per segment: 1024, for targets below 8192 rows 512; from four segments up
+      uint32_t rows = opt.seg_rows > 0 ? (uint32_t)round_up((size_t)opt.seg_rows, 64) : a.max_t >= 8192 ? 1024 : 512;
       rows = std::max<uint32_t>(rows, (uint32_t)round_up(((size_t)a.max_t + kMaxSegments - 1) / kMaxSegments, 64));
       const uint32_t nseg = (a.max_t + rows - 1) / rows;
       const size_t state_words = seg_state_words(a.pairs_in_pass, nseg) + 1;
-      const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 8 && a.cigar_stride / nseg >= 64 &&
+      const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 4 && a.cigar_stride / nseg >= 64 &&
                             a.cigar_stride / nseg <= 0xFFFFFFFFull &&
                             state_words <= (size_t)a.pairs_in_pass * a.brow_unit_stride &&
                             (size_t)a.pairs_in_pass * nseg < ((size_t)1 << 31);

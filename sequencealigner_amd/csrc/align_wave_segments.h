@@ -6,7 +6,7 @@
 //   * the target rows are cut into segments of `rows` rows, one wavefront each.  A segment's walk starts on
 //     its top row (the topmost segment: at the end cell) and stops at the first cell it reaches on the top row
 //     of the segment below; its runs go to the segment's own part of the pair's run slot;
-//   * every segment walks at once from a GUESSED start column (the straight line to the end cell) and publishes
+//   * every segment walks at once from a GUESSED start column (on or to the right of the likely path) and publishes
 //     the column it lands on, marked "speculative".  A segment that sees the segment above publish a column other
 //     than the one it started from walks again from that column.  The topmost segment's landing is final; a
 //     segment whose upstream landing is final AND equal to the column it last started from marks its own
@@ -109,8 +109,17 @@ __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegAr
   bool pending = true;
   if (k < ktop) {
     pending = sg.spec_walks && (uint32_t)(upstream() >> 32) == SEG_NONE;
-    if (pending) {  // nothing known yet: the straight line to the end cell
-      next_col = (uint32_t)((uint64_t)hi * Q / i_end);
+    if (pending) {
+      // Nothing known yet.  A walk that starts to the RIGHT of the path reaches it along its own row (a run of
+      // Left moves, 64 per iteration, no target row used up), one that starts to the left of it needs Up moves
+      // and may leave the segment before it gets there: so the guess is the rightmost of three lines - the
+      // straight line from the origin to the end cell and the diagonals through the origin and the end cell.
+      const uint64_t straight = (uint64_t)hi * Q / i_end;
+      const uint64_t from_origin = hi;
+      const uint64_t from_end = (uint64_t)Q + hi > i_end ? (uint64_t)Q + hi - i_end : 0;
+      const uint64_t right = straight > from_origin ? (straight > from_end ? straight : from_end)
+                                                    : (from_origin > from_end ? from_origin : from_end);
+      next_col = (uint32_t)(right < Q ? right : Q);
       next_state = SEG_SPECULATIVE;
     }
   }
