@@ -77,6 +77,8 @@ const char* sa_device_arch(int device);
  *                                      not by one wavefront per segment of target rows
  *   "seg_rows"      (SA_SEG_ROWS)      target rows per such segment, 0 automatic (1024, more for targets
  *                                      beyond 1 M rows)
+ *   "spin_limit"    (SA_SPIN_LIMIT)    polls a wait inside a cooperative kernel may take before the kernels give up
+ *                                      and the call fails with SA_ERR_HIP (default 2^24; a small value is a test hook)
  *   "seg_spec"      (SA_SEG_SPEC)      walks a segment may make from columns that are not final yet (default 2)
  *   "seg_cap"       (SA_SEG_CAP)       runs a segment may hold, 0: its share of the pair's run slot; a small
  *                                      value sends pairs to the one-wavefront walk (a test hook)

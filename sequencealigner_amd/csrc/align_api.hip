@@ -52,6 +52,7 @@ Options& options() {
     x->seg_rows = num("SA_SEG_ROWS", 0);
     x->seg_cap = num("SA_SEG_CAP", 0);
     x->seg_spec = num("SA_SEG_SPEC", 2);
+    x->spin_limit = num("SA_SPIN_LIMIT", 1 << 24);
     x->fake_devices = num("SA_FAKE_DEVICES", 0);
     return x;
   }();
@@ -496,6 +497,7 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
         sg.redo = sg.seg_nruns + (size_t)a.pairs_in_pass * nseg;
         sg.ticket = sg.redo + a.pairs_in_pass;
         sg.abort_flag = co.abort_flag;
+        sg.spin_limit = co.spin_limit;
         sg.spec_walks = (uint32_t)std::max(0L, std::min(8L, (long)opt.seg_spec));
         hipLaunchKernelGGL(clear_words, dim3((unsigned)((state_words + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<uint32_t*>(a.brow), (uint32_t)state_words);
@@ -585,7 +587,8 @@ int sa_set_option(const char* name, long value) {
                {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
-               {"seg_cap", &o.seg_cap},     {"seg_spec", &o.seg_spec}};
+               {"seg_cap", &o.seg_cap},     {"seg_spec", &o.seg_spec},
+               {"spin_limit", &o.spin_limit}};
   for (auto& e : table)
     if (!strcmp(name, e.name)) {
       *e.slot = value;
@@ -821,6 +824,8 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     co.ticket = (uint32_t*)d_workspace;  // head of the workspace (the packed kernels keep their table there)
     co.abort_flag = (int*)d_workspace + 1;
     co.cand = (int32_t*)w;
+    co.spin_limit = (uint32_t)std::max(1L, std::min((long)kSpinLimit, (long)options().spin_limit));
+    a.gave_up = co.abort_flag;
     SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
     // Wavefronts of one pass.  They need not all be resident: strips take their numbers from a ticket counter in
     // start order, so a strip only ever waits for strips that already run (Local: one pass, all resident).
@@ -852,7 +857,7 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     int aborted = 0;
     SA_HIP_TRY(hipMemcpyAsync(&aborted, co.abort_flag, 4, hipMemcpyDeviceToHost, stream));
     SA_HIP_TRY(hipStreamSynchronize(stream));
-    if (aborted) return fail(SA_ERR_HIP, "cooperative fill: a strip waited too long for its neighbour");
+    if (aborted) return fail(SA_ERR_HIP, "cooperative kernels: a strip or a traceback segment waited too long for its neighbour");
   }
   return SA_OK;
 }

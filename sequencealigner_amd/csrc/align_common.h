@@ -41,6 +41,9 @@ struct AlignArgs {
   const struct AlphabetInfo* rec_alpha;  // the records are valid when small && !violated
   // traceback_wave: when set, only the pairs (of the pass) with a nonzero word are walked
   const uint32_t* tb_only;
+  // cooperative kernels: set when a wait ran out; the fill's results are then incomplete and the traceback
+  // kernels return at once (the call fails)
+  const int* gave_up;
 };
 
 // Border values of the DP matrix, rows = target (index i), columns = query (index r).

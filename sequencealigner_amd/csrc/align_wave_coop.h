@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
   auto poll_entries = [&](uint32_t b0, uint64_t& e) -> bool {
     for (uint32_t polls = 0; !entries_ready(b0, e); ++polls) {
       __builtin_amdgcn_s_sleep(1);
-      if (polls >= kSpinLimit ||
+      if (polls >= co.spin_limit ||
           ((polls & 1023u) == 1023u && __hip_atomic_load(co.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;

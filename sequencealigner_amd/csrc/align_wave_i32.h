@@ -108,6 +108,7 @@ struct WaveCoop {
   uint32_t* ticket;    // one counter per launch
   int* abort_flag;     // set when a bounded wait ran out
   int32_t* cand;       // [pair][strip][3]: Local candidates (score, row, column)
+  uint32_t spin_limit; // polls a wait may take before it gives up (kSpinLimit; the option "spin_limit" lowers it)
 };
 
 constexpr uint32_t kSpinLimit = 1u << 24;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64) void fill_wave_i32(AlignArgs a, WaveCoop co, ui
           if (want) e = __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!COOP || __all(!want || (uint32_t)(e >> 32) == s)) break;
           __builtin_amdgcn_s_sleep(1);
-          if (polls >= kSpinLimit ||
+          if (polls >= co.spin_limit ||
               ((polls & 1023u) == 1023u &&
                __hip_atomic_load(co.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -732,11 +733,13 @@ __global__ __launch_bounds__(64) void traceback_wave(AlignArgs a) {
   const uint32_t pl = blockIdx.x;
   if (pl >= a.pairs_in_pass) return;
   if (a.tb_only && !a.tb_only[pl]) return;
+  if (a.gave_up && *a.gave_up) return;
   const uint32_t p = a.pair_base + pl;
   const uint32_t Q = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
   const uint32_t T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
-  const uint32_t i = (MODE == SA_GLOBAL) ? T : a.end_i[pl];
-  const uint32_t r = (MODE == SA_LOCAL) ? a.end_r[pl] : Q;
+  // (the end cell lies inside the matrix whatever the fill left behind)
+  const uint32_t i = (MODE == SA_GLOBAL) ? T : min(a.end_i[pl], T);
+  const uint32_t r = (MODE == SA_LOCAL) ? min(a.end_r[pl], Q) : Q;
   uint32_t* slot_end = a.cigar_runs ? a.cigar_runs + (uint64_t)(p + 1) * a.cigar_stride : nullptr;
   const WalkEnd e = walk_wave<MODE, Fmt>(a, pl, i, r, 0, slot_end, ~0u, ~0u);
   if (threadIdx.x != 0) return;

@@ -44,6 +44,7 @@ struct SegArgs {
   uint32_t* redo;       // [pair of the pass]: nonzero = walk this pair with one wavefront instead; zero at launch
   uint32_t* ticket;     // zero at launch
   int* abort_flag;
+  uint32_t spin_limit;  // polls a wait may take before it gives up
 };
 
 // words to clear before a launch, starting at SegArgs::pub (the three arrays are laid out back to back)
@@ -55,6 +56,7 @@ template <int MODE, class Fmt>
 __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegArgs sg) {
   static_assert(MODE != SA_LOCAL, "Global and Semiglobal only");
   const uint32_t lane = threadIdx.x;
+  if (a.gave_up && *a.gave_up) return;  // the fill is incomplete: nothing to walk
   uint32_t ticket = 0;
   if (lane == 0) ticket = atomicAdd(sg.ticket, 1u);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegAr
   const uint32_t p = a.pair_base + pl;
   const uint32_t Q = (uint32_t)(a.q_off[p + 1] - a.q_off[p]);
   const uint32_t T = (uint32_t)(a.t_off[p + 1] - a.t_off[p]);
-  const uint32_t i_end = __builtin_amdgcn_readfirstlane((MODE == SA_GLOBAL) ? T : a.end_i[pl]);
+  const uint32_t i_end = __builtin_amdgcn_readfirstlane((MODE == SA_GLOBAL) ? T : min(a.end_i[pl], T));
   const uint32_t ktop = i_end ? (i_end - 1) / sg.rows : 0;
   if (k > ktop) return;  // above the end cell: no runs (seg_nruns stays 0)
   const uint32_t lo = k * sg.rows;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64) void traceback_wave_segments(AlignArgs a, SegAr
       const bool fresh = state == SEG_FINAL || (state == SEG_SPECULATIVE && spec_left && !(walked && col == used));
       if (!fresh) {
         __builtin_amdgcn_s_sleep(2);
-        if (++polls >= kSpinLimit ||
+        if (++polls >= sg.spin_limit ||
             ((polls & 1023u) == 1023u && __hip_atomic_load(sg.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           __hip_atomic_store(sg.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(1024) void stitch_segments(AlignArgs a, SegArgs sg)
   __shared__ uint32_t patch_at[kMaxSegments], patch_val[kMaxSegments];
   __shared__ uint32_t s_total, s_np;
   const uint32_t pl = blockIdx.x, tid = threadIdx.x;
-  if (pl >= a.pairs_in_pass || sg.redo[pl]) return;
+  if (pl >= a.pairs_in_pass || sg.redo[pl] || (a.gave_up && *a.gave_up)) return;
   const uint32_t p = a.pair_base + pl;
   uint32_t* slot = a.cigar_runs + (uint64_t)p * a.cigar_stride;
   const uint32_t K = sg.nseg;

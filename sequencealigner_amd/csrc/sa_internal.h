@@ -48,6 +48,8 @@ struct Options {
   std::atomic<long> no_buckets{0};    // SA_NO_BUCKETS: single sequences take the device-wide radix sort
   std::atomic<long> no_segments{0};   // SA_NO_SEGMENTS: long pairs are traced back by one wavefront each
   std::atomic<long> seg_rows{0};      // SA_SEG_ROWS: target rows per traceback segment (0 automatic)
+  std::atomic<long> spin_limit{1 << 24}; // SA_SPIN_LIMIT: polls a wait inside a cooperative kernel may take before
+                                      // the kernels give up and the call fails (a small value: test hook)
   std::atomic<long> seg_spec{2};      // SA_SEG_SPEC: walks a traceback segment may make on speculative columns
   std::atomic<long> seg_cap{0};       // SA_SEG_CAP: runs a traceback segment may hold (0: its share of the slot);
                                       // a small value sends pairs to the one-wavefront walk (a test hook)

@@ -455,6 +455,31 @@ def test_segmented_traceback_vs_oracle(oracle, cap):
         _force_family(None)
 
 
+def test_cooperative_wait_that_runs_out_fails_the_call(oracle):
+    """Every wait inside the cooperative kernels is bounded.  With the bound at one poll (a host-side option;
+    the kernels still run to their end) a strip finds its neighbour's rows missing and gives up, the others
+    follow, and the call reports it instead of returning a wrong result.  The next call, with the usual bound,
+    is unaffected."""
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    qq, tt = synth.pair_global_long(6000, seed=41)
+    q, t = bytes(qq).decode(), bytes(tt[:5600]).decode()
+    for typ, (m, x, g) in ((0, (1, -1, -1)), (2, (1, -1, -1)), (1, (2, -3, -2))):
+        b = align.DeviceAlignBatch([q], [t], typ, m, x, g)
+        assert b.kernel_name() == "wave_i32_coop"
+        capi.set_option("spin_limit", 1)
+        try:
+            with pytest.raises(capi.SaError, match="waited too long"):
+                b.run()
+        finally:
+            capi.set_option("spin_limit", 1 << 24)
+        torch.cuda.synchronize()
+        b.run()
+        torch.cuda.synchronize()
+        want = oracle.align(q, t, typ, m, x, g)
+        assert (int(b.scores()[0]), b.cigars([0])[0], int(b.target_begins()[0])) == want
+
+
 def test_empty_and_odd_batches_vs_oracle(oracle, family):
     """Empty queries / targets next to ordinary pairs, and batches of 1 and 3 pairs (a packed wavefront or
     lane then holds a pair without a partner); the meaning of the empty cases is the one the CPU
