@@ -599,7 +599,8 @@ struct EmitArgs {
 
 __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   // one buffer, two uses: [0, 4096) grouped keys + [4096, 5120) bin counters (16 bits each, two per dword)
-  // while sorting, then the staged (value, position << 1 | strand) pairs.  20 KB: eight blocks per CU.
+  // while sorting, then the staged (value, position << 1 | strand) pairs.  20.3 KB with the small arrays below
+  // and 65 registers: seven blocks per CU (a leaner form that fits eight ran no faster).
   __shared__ __attribute__((aligned(16))) uint32_t buf[2 * kSmallMax + kBins / 2];
   __shared__ uint32_t lds[kThreads / 64];
   __shared__ uint32_t dup_rank[64];  // ranks of keys that repeat their predecessor (few, if any)
