@@ -478,7 +478,12 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
       rows = std::max<uint32_t>(rows, (uint32_t)round_up(((size_t)a.max_t + kMaxSegments - 1) / kMaxSegments, 64));
       const uint32_t nseg = (a.max_t + rows - 1) / rows;
       const size_t state_words = seg_state_words(a.pairs_in_pass, nseg) + 1;
-      const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 4 && a.cigar_stride / nseg >= 64 &&
+      // Worth it when the path spans four segments or more (a Semiglobal path has about as many rows as the
+      // query has columns, however long the target) and the pairs of the pass are too few to fill the GPU with
+      // one wavefront each (400 pairs of 500 x 5000: 0.05 ms that way, 0.19 ms in segments).
+      const uint32_t path_rows = MODE == SA_SEMIGLOBAL ? std::min(a.max_q, a.max_t) : a.max_t;
+      const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 4 && path_rows >= 4 * rows &&
+                            (a.pairs_in_pass <= 256 || opt.seg_rows > 0) && a.cigar_stride / nseg >= 64 &&
                             a.cigar_stride / nseg <= 0xFFFFFFFFull &&
                             state_words <= (size_t)a.pairs_in_pass * a.brow_unit_stride &&
                             (size_t)a.pairs_in_pass * nseg < ((size_t)1 << 31);
