@@ -419,14 +419,18 @@ def minimizer_leg(dev, steps, cpu_threads, with_cpu):
             off = np.arange(sample, dtype=np.uint64) * np.uint64(blob.shape[1])
             lens = np.full(sample, seqs.shape[1], dtype=np.uint32)
             t0 = time.perf_counter()
-            counts = chk.minimize_batch(blob.reshape(-1), off, lens, 15, 5, cpu_threads)
+            counts, hashes = chk.minimize_batch(blob.reshape(-1), off, lens, 15, 5, cpu_threads)
             cdt = time.perf_counter() - t0
+            cpu_checker, _ = cpu_checker_lib()
+            gpu_hashes = cpu_checker.triple_list_hashes(b.d_out, b.d_out_off)[:sample]
             win = sample * (seqs.shape[1] - 18)
             out[name]["cpu_baseline"] = {
                 "value": win / cdt, "unit": "windows/s", "cores": cpu_threads, "cores_on_box": os.cpu_count(),
                 "kind": "reference" if chk.kind == "reference" else "port",
                 "sample": f"{sample} reads of the same workload, {cdt:.1f} s",
-                "counts_equal_gpu": bool(np.array_equal(counts.astype(np.int64), b.counts()[:sample]))}
+                # every read's list: equal length and equal hash over its (value, position, strand) entries
+                "triples_equal_gpu": bool(np.array_equal(counts.astype(np.int64), b.counts()[:sample]) and
+                                          np.array_equal(hashes, gpu_hashes))}
         del b
         torch.cuda.empty_cache()
     return out

@@ -95,10 +95,14 @@ int sa_set_option(const char* name, long value);
  * src/alignment.cpp:63,176,281); pair p has query d_q[q_off[p] .. q_off[p+1]) and target
  * d_t[t_off[p] .. t_off[p+1]).  All d_* pointers are device pointers on `device`; `stream` is a
  * hipStream_t (NULL = default stream).  d_q and d_t must be readable up to 8 bytes past their last
- * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except for
- * batches of few pairs (hundreds, not thousands) of more than a few hundred symbols, which run cooperatively
- * (kernel name "wave_i32_coop", see sa_align_kernel_name) and synchronise the stream once at the end to read
- * the kernels' abort flag; sa_align_batch_device_static never does.
+ * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except where
+ * it runs the cooperative kernels, which synchronise the stream once at the end to read their abort flag:
+ * batches of few pairs (hundreds, not thousands) of more than a few hundred symbols (kernel name
+ * "wave_i32_coop", see sa_align_kernel_name), and batches of long pairs that need several passes over the
+ * workspace and leave at most 768 pairs for the last pass - those pairs (and a head of few pairs) are
+ * planned again as batches of their own and may take the cooperative kernels although the batch's kernel
+ * name says "wave_pk16" / "wave_i32".  sa_align_may_synchronize tells which it will be for a batch and a
+ * workspace size; sa_align_batch_device_static never synchronises.
  *
  * The batch is planned for max_qlen x max_tlen: every pair pays for direction words and steps of that shape.
  * Callers with mixed sizes should issue one call per size class (sa_align_batch_host does).
@@ -158,6 +162,16 @@ int sa_align_batch_device(int device, void* stream, const sa_align_batch* batch,
  * caller.  sa_align_profile() must be off (its timing events are allocations). */
 size_t sa_align_static_scratch_bytes(void);
 int sa_align_batch_device_static(int device, void* stream, const sa_align_batch* batch);
+/* Looks up the array's address on `device` (hipGetSymbolAddress, which may load the code object on that GPU).
+ * sa_align_batch_device_static does the same on its first call per GPU; callers that capture the call into a
+ * HIP graph call this once per GPU beforehand, outside the capture.  (No counterpart in the reference.) */
+int sa_align_static_init(int device);
+
+/* 1 when sa_align_batch_device would synchronise `stream` for this batch over a workspace of
+ * `workspace_bytes` (it runs cooperative kernels for the batch or for a part of it), else 0: such a call
+ * must not be captured into a graph or relied on to return before its kernels have run.  Only the batch's
+ * n, type, scoring and maximum lengths are read.  (No counterpart in the reference.) */
+int sa_align_may_synchronize(int device, const sa_align_batch* batch, size_t workspace_bytes);
 
 /* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32", "wave_i32",
  * "wave_i32_coop"), for logs and profiles. */

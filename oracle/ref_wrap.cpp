@@ -113,9 +113,17 @@ int sa_cpu_align_batch(const char* q_blob, const uint64_t* q_off, const char* t_
 }
 
 int sa_cpu_minimize_batch(const char* blob, const uint64_t* off, const uint32_t* len, size_t n,
-                          uint32_t kmer_len, uint32_t window_len, int threads, uint64_t* counts) {
+                          uint32_t kmer_len, uint32_t window_len, int threads, uint64_t* counts,
+                          uint64_t* hashes) {
   task_farm(n, threads, [&](size_t i) {
-    counts[i] = MinimizeBinary(blob + off[i], len[i], kmer_len, window_len).size();
+    std::vector<Tuple> list = MinimizeBinary(blob + off[i], len[i], kmer_len, window_len);
+    counts[i] = list.size();
+    if (hashes) {
+      uint64_t h = 0;
+      for (size_t x = 0; x < list.size(); ++x)
+        h += sa_triple_hash(std::get<0>(list[x]), std::get<1>(list[x]), std::get<2>(list[x]) ? 1u : 0u, x);
+      hashes[i] = h;
+    }
   });
   return 0;
 }

@@ -18,6 +18,19 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Hash of entry `index` of a minimizer list (the splitmix64 finalizer over the packed entry plus a multiple
+ * of the index), summed over a list by sa_cpu_minimize_batch. */
+static inline uint64_t sa_triple_hash(uint32_t value, uint32_t pos, uint32_t strand, uint64_t index) {
+  uint64_t x = ((uint64_t)value | ((uint64_t)pos << 32) | ((uint64_t)strand << 63)) +
+               0x9E3779B97F4A7C15ull * (index + 1);
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -66,9 +79,12 @@ int sa_cpu_align_batch(const char* q_blob, const uint64_t* q_off, const char* t_
                        int want_cigar, int threads, int32_t* scores, uint32_t* target_begin);
 
 /* Task farm over independent NUL-terminated sequences (seq i = blob + off[i], length len[i]).
- * counts[i] receives the number of minimizers of sequence i.  Returns 0. */
+ * counts[i] receives the number of minimizers of sequence i and, when hashes is not NULL, hashes[i] the
+ * sum (mod 2^64) of sa_triple_hash over the list's entries in list order: two lists with equal count and
+ * hash are equal entry for entry, up to a 2^-64 chance.  Returns 0. */
 int sa_cpu_minimize_batch(const char* blob, const uint64_t* off, const uint32_t* len, size_t n,
-                          uint32_t kmer_len, uint32_t window_len, int threads, uint64_t* counts);
+                          uint32_t kmer_len, uint32_t window_len, int threads, uint64_t* counts,
+                          uint64_t* hashes);
 
 /* "restatement" or "reference" */
 /* Restates getAlignmentBlockLengthAndMatchLength (reference src/mapper.cpp:371-399): *abl = sum of the

@@ -68,6 +68,8 @@ SYMBOLS = [
      [C.c_int, C.c_void_p, C.POINTER(AlignBatch), C.c_void_p, C.c_size_t]),
     ("sa_align_static_scratch_bytes", C.c_size_t, []),
     ("sa_align_batch_device_static", C.c_int, [C.c_int, C.c_void_p, C.POINTER(AlignBatch)]),
+    ("sa_align_static_init", C.c_int, [C.c_int]),
+    ("sa_align_may_synchronize", C.c_int, [C.c_int, C.POINTER(AlignBatch), C.c_size_t]),
     ("sa_align_kernel_name", C.c_char_p, [C.POINTER(AlignBatch)]),
     ("sa_align_profile", C.c_int, [C.c_int]),
     ("sa_align_profile_read", C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

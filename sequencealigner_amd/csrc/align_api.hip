@@ -694,6 +694,51 @@ int static_scratch(int device, void** out) {
 int align_batch_device(int device, void* stream_, const sa_align_batch* b, void* d_workspace, size_t workspace_bytes,
                        bool static_scratch_call);
 
+// Blocks of pairs one pass over a workspace of `workspace_bytes` (>= the plan's minimum) holds.
+size_t blocks_in_a_pass(const Plan& pl, const sa_align_batch& b, size_t workspace_bytes, int device) {
+  const size_t total_blocks = ((size_t)b.n + pl.pairs_per_block - 1) / pl.pairs_per_block;
+  size_t blocks_per_pass = (workspace_bytes - kFixedWorkspace) / pl.bytes_per_block;
+  if (blocks_per_pass > total_blocks) blocks_per_pass = total_blocks;
+  // a pass stays within the grid limits of its launches (65 535 in y for the packing kernel's units, 2^32
+  // threads in all for the one-wavefront-per-pair kernels)
+  const size_t max_blocks = std::max<size_t>(1, ((size_t)1 << 22) / pl.pairs_per_block);
+  if (blocks_per_pass > max_blocks) blocks_per_pass = max_blocks;
+  if (pl.family == Family::WaveI32 && !pl.coop && blocks_per_pass < total_blocks) {
+    // One wavefront per unit, all of about the same duration: a pass takes as long as the SIMD with the most
+    // wavefronts, so a pass that is cut by the workspace holds a whole number of wavefronts per SIMD
+    // (3200 wavefronts on 1024 SIMDs take four rounds, 3072 take three).
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    const size_t simds = (size_t)cus * 4;
+    if (blocks_per_pass >= simds) blocks_per_pass = blocks_per_pass / simds * simds;
+  }
+  return blocks_per_pass;
+}
+
+// Pairs of a several-pass batch of the one-wavefront-per-pair kernels that are planned again as a batch of their
+// own (0: none): the last pass's pairs when they are too few to fill the GPU.
+size_t leftover_pairs(const Plan& pl, const sa_align_batch& b, size_t pairs_per_pass, bool static_scratch_call) {
+  if (pl.family != Family::WaveI32 || pl.coop || static_scratch_call || b.n <= pairs_per_pass) return 0;
+  const size_t rest = b.n % pairs_per_pass;
+  return rest <= 768 ? rest : 0;
+}
+
+// Whether align_batch_device would run cooperative kernels (and therefore synchronise the stream) for this batch
+// over a workspace of this size: directly, or for the head or the left-over pairs of a several-pass batch.
+bool batch_synchronises(const sa_align_batch& b, size_t workspace_bytes, int device) {
+  if (b.n == 0 || b.type < 0 || b.type > 2) return false;
+  const Plan pl = make_plan(b, true);
+  if (pl.coop) return true;
+  if (workspace_bytes < pl.bytes_per_block + kFixedWorkspace) return false;  // the call fails before any launch
+  const size_t pairs_per_pass = blocks_in_a_pass(pl, b, workspace_bytes, device) * pl.pairs_per_block;
+  const size_t rest_n = leftover_pairs(pl, b, pairs_per_pass, false);
+  if (!rest_n) return false;
+  sa_align_batch head = b, rest = b;
+  head.n = (uint32_t)(b.n - rest_n);
+  rest.n = (uint32_t)rest_n;
+  return batch_synchronises(head, workspace_bytes, device) || batch_synchronises(rest, workspace_bytes, device);
+}
+
 }  // namespace
 }  // namespace sa
 
@@ -705,6 +750,17 @@ int sa_align_batch_device(int device, void* stream_, const sa_align_batch* b, vo
 }
 
 size_t sa_align_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int sa_align_may_synchronize(int device, const sa_align_batch* b, size_t workspace_bytes) {
+  if (!b) return 0;
+  return batch_synchronises(*b, workspace_bytes, device) ? 1 : 0;
+}
+
+int sa_align_static_init(int device) {
+  SA_HIP_TRY(hipSetDevice(device));
+  void* p = nullptr;
+  return static_scratch(device, &p);
+}
 
 int sa_align_batch_device_static(int device, void* stream, const sa_align_batch* b) {
   return align_batch_device(device, stream, b, nullptr, 0, true);
@@ -745,31 +801,15 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
   if (!d_workspace || workspace_bytes < pl.bytes_per_block + kFixedWorkspace)
     return fail(SA_ERR_WORKSPACE, "workspace of %zu bytes is below the minimum %zu", workspace_bytes,
                 pl.bytes_per_block + kFixedWorkspace);
-  const size_t total_blocks = ((size_t)b->n + pl.pairs_per_block - 1) / pl.pairs_per_block;
-  size_t blocks_per_pass = (workspace_bytes - kFixedWorkspace) / pl.bytes_per_block;
-  if (blocks_per_pass > total_blocks) blocks_per_pass = total_blocks;
-  // a pass stays within the grid limits of its launches (65 535 in y for the packing kernel's units, 2^32
-  // threads in all for the one-wavefront-per-pair kernels)
-  const size_t max_blocks = std::max<size_t>(1, ((size_t)1 << 22) / pl.pairs_per_block);
-  if (blocks_per_pass > max_blocks) blocks_per_pass = max_blocks;
-  if (pl.family == Family::WaveI32 && !pl.coop && blocks_per_pass < total_blocks) {
-    // One wavefront per unit, all of about the same duration: a pass takes as long as the SIMD with the most
-    // wavefronts, so a pass that is cut by the workspace holds a whole number of wavefronts per SIMD
-    // (3200 wavefronts on 1024 SIMDs take four rounds, 3072 take three).
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    const size_t simds = (size_t)cus * 4;
-    if (blocks_per_pass >= simds) blocks_per_pass = blocks_per_pass / simds * simds;
-  }
+  const size_t blocks_per_pass = blocks_in_a_pass(pl, *b, workspace_bytes, device);
   const size_t units_per_pass = blocks_per_pass * pl.units_per_block;
   size_t pairs_per_pass = blocks_per_pass * pl.pairs_per_block;
 
   // One wavefront per pair in several passes: the pairs left over for the last pass are a batch of their own,
   // planned anew - a few hundred of them are too few wavefronts for these kernels (424 pairs of 10 kbp x 11 kbp
   // take as long as 2048) and run on the cooperative kernel instead.
-  if (pl.family == Family::WaveI32 && !pl.coop && !static_scratch_call && b->n > pairs_per_pass &&
-      b->n % pairs_per_pass != 0 && b->n % pairs_per_pass <= 768) {
-    const size_t rest_n = b->n % pairs_per_pass, head_n = b->n - rest_n;
+  if (const size_t rest_n = leftover_pairs(pl, *b, pairs_per_pass, static_scratch_call)) {
+    const size_t head_n = b->n - rest_n;
     sa_align_batch head = *b, rest = *b;
     head.n = (uint32_t)head_n;
     rest.n = (uint32_t)rest_n;
@@ -833,7 +873,7 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     a.gave_up = co.abort_flag;
     SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
     // Wavefronts of one pass.  They need not all be resident: strips take their numbers from a ticket counter in
-    // start order, so a strip only ever waits for strips that already run (Local: one pass, all resident).
+    // start order, so a strip only ever waits for strips that already run.
     const size_t coop_waves = (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
     const size_t cap = std::max<size_t>(1, coop_waves / pl.nstrips);
     if (pairs_per_pass > cap) pairs_per_pass = cap;

@@ -178,6 +178,14 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
     }
     return true;
   };
+  // Lanes hand values to other lanes of the wavefront through LDS (stage_rows -> batch, step -> publish).  The
+  // hardware keeps a wavefront's LDS accesses in program order; this keeps the compiler from moving a load
+  // above the stores of other lanes it reads (it could prove the addresses of ONE lane disjoint).  No
+  // instruction is emitted for either builtin.
+  auto lds_handoff = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   // hands the fetched rows b0 .. b0 + 31 (b0 = 1 + 32 m) to the steps
   auto stage_rows = [&](uint32_t b0, int words, int entry) __attribute__((always_inline)) {
     if (lane < kCoopFetch) {
@@ -186,6 +194,7 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
       trows[at + kCoopRing] = words;
       bleft[(((b0 - 1) / kCoopFetch) & 1u) * kCoopFetch + lane] = entry;
     }
+    lds_handoff();
   };
 
   // One step at position X of its batch.  FULL: every lane has a valid row, nothing is predicated.
@@ -260,12 +269,14 @@ __global__ __launch_bounds__(64) void fill_wave_coop2(AlignArgs a, WaveCoop co, 
 
   auto publish = [&](uint32_t b0) __attribute__((always_inline)) {
     // lane 63 finished the rows b0 - 63 .. b0 - 48 in this batch; lanes 47..62 pick them up and store them
+    lds_handoff();
     if (!last_strip) {
       const uint32_t row = b0 + lane - 110;
       if (lane >= 47 && lane <= 62 && b0 + lane >= 111 && row <= T)
         __hip_atomic_store(&bout_p[row], ((uint64_t)(s + 1) << 32) | (uint32_t)lastcols[(lane - 47) * 64 + 63],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    lds_handoff();  // the next batch's steps overwrite what these lanes have just read
   };
   // One batch of 16 steps.
   auto run_batch = [&](uint32_t b0, uint32_t half) __attribute__((always_inline)) {

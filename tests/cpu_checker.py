@@ -32,7 +32,7 @@ class CpuChecker:
                                          C.c_void_p, C.c_void_p]
         L.sa_cpu_minimize_batch.restype = C.c_int
         L.sa_cpu_minimize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                            C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+                                            C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         if hasattr(L, "sa_cpu_score_linear"):
             L.sa_cpu_score_linear.restype = C.c_int
             L.sa_cpu_score_linear.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int,
@@ -164,13 +164,46 @@ class CpuChecker:
         return scores, tb
 
     def minimize_batch(self, blob, off, lens, k, w, threads):
+        """-> (counts, hashes): per sequence the length of its minimizer list and the list's hash (the sum of
+        sa_triple_hash over its entries, oracle/sa_oracle.h); `triple_list_hashes` computes the same figure
+        from a device result."""
         n = len(lens)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         counts = np.zeros(n, dtype=np.uint64)
+        hashes = np.zeros(n, dtype=np.uint64)
         self.lib.sa_cpu_minimize_batch(blob.ctypes.data, off.ctypes.data, lens.ctypes.data, n, k, w,
-                                       threads, counts.ctypes.data)
-        return counts
+                                       threads, counts.ctypes.data, hashes.ctypes.data)
+        return counts, hashes
+
+
+def _i64(x):
+    """The 64-bit pattern x as a signed Python int (torch has no unsigned 64-bit arithmetic)."""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >> 63 else x
+
+
+def triple_list_hashes(d_out, d_out_off):
+    """Per-sequence hashes of minimizer lists that lie in device memory (d_out: int32 [3 * total] of
+    (value, position, strand) triples, d_out_off: int64 [n + 1]), computed with torch on that device:
+    the sum modulo 2^64 of sa_triple_hash (oracle/sa_oracle.h) over every list.  -> uint64 numpy array [n]."""
+    import torch
+    total = int(d_out_off[-1].item())
+    n = d_out_off.numel() - 1
+    tri = d_out[: 3 * total].reshape(-1, 3).to(torch.int64) & 0xFFFFFFFF
+    first = d_out_off[:-1]
+    counts = d_out_off[1:] - first
+    seq = torch.repeat_interleave(torch.arange(n, device=d_out.device), counts)
+    index = torch.arange(total, device=d_out.device) - first[seq]
+    x = (tri[:, 0] | (tri[:, 1] << 32) | (tri[:, 2] << 63)) + (index + 1) * _i64(0x9E3779B97F4A7C15)
+    x = x ^ ((x >> 30) & ((1 << 34) - 1))
+    x = x * _i64(0xBF58476D1CE4E5B9)
+    x = x ^ ((x >> 27) & ((1 << 37) - 1))
+    x = x * _i64(0x94D049BB133111EB)
+    x = x ^ ((x >> 31) & ((1 << 33) - 1))
+    sums = torch.zeros(n, dtype=torch.int64, device=d_out.device)
+    sums.index_add_(0, seq, x)
+    return sums.cpu().numpy().view(np.uint64)
 
 
 def _build(target):

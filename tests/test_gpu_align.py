@@ -174,6 +174,10 @@ def test_leftover_pairs_of_the_last_pass(oracle):
                 per_block = mn.value - 1024          # the minimum is one block of two pairs plus the fixed head
                 del probe
                 b = align.DeviceAlignBatch(q, t, typ, 1, -1, -1, workspace_bytes=1024 + 128 * per_block)
+                # the left-over pairs take the cooperative kernel, which synchronises: the query says so, while
+                # the same batch over a workspace that holds it in one pass only enqueues work
+                assert capi.lib().sa_align_may_synchronize(0, C.byref(b.batch), b.workspace_bytes) == (coop != 0)
+                assert capi.lib().sa_align_may_synchronize(0, C.byref(b.batch), 1 << 34) == 0
                 b.run()
                 torch.cuda.synchronize()
             finally:

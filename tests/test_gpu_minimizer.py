@@ -84,8 +84,34 @@ def test_genome_and_reads_shapes_vs_oracle(oracle):
     assert np.array_equal(got, want)
     reads = synth.reads(300, 10_000, seed=74)
     res = minimize.minimize_batch(reads, 15, 5)
-    for i in range(0, 300, 17):
-        assert np.array_equal(res[i], oracle.minimize_binary_array(bytes(reads[i]), 15, 5))
+    for i in range(300):
+        assert np.array_equal(res[i], oracle.minimize_binary_array(bytes(reads[i]), 15, 5)), i
+
+
+def test_benchmark_inputs_every_triple_vs_oracle(oracle):
+    """The benchmark's own minimizer inputs at full size (bench.py::minimizer_leg): the 4.6 Mbp genome compared
+    triple for triple, and all 100 000 reads of 10 kbp compared through the count and the hash of every read's
+    list (the CPU checker hashes the list it computed, cpu_checker.triple_list_hashes the device result), with
+    every 997th read's list compared in full."""
+    import cpu_checker
+    from sequencealigner_amd import minimize, synth
+    g = bytes(synth.genome(4_600_000, seed=4))
+    assert np.array_equal(minimize.minimize_binary(g, 15, 5), oracle.minimize_binary_array(g, 15, 5))
+    reads = synth.reads(100_000, 10_000, seed=6)
+    n, length = reads.shape
+    b = minimize.DeviceMinimizeBatch(reads, 15, 5)
+    b.run()
+    assert b.status() == 0
+    got_hash = cpu_checker.triple_list_hashes(b.d_out, b.d_out_off)
+    got_count = b.counts()
+    blob = np.concatenate([reads, np.zeros((n, 1), np.uint8)], axis=1)   # NUL-terminated, as the reference reads them
+    off = np.arange(n, dtype=np.uint64) * np.uint64(length + 1)
+    want_count, want_hash = oracle.minimize_batch(blob.reshape(-1), off, np.full(n, length, np.uint32), 15, 5, 16)
+    assert np.array_equal(got_count.astype(np.uint64), want_count)
+    assert np.array_equal(got_hash, want_hash)
+    res = b.results()
+    for i in range(0, n, 997):
+        assert np.array_equal(res[i], oracle.minimize_binary_array(bytes(reads[i]), 15, 5)), i
 
 
 def test_sortedness_and_uniqueness_property():

@@ -80,3 +80,46 @@ def test_static_scratch_entry_point_equals_workspace_entry_point(oracle):
     assert rc == capi.SA_ERR_WORKSPACE
     assert b"static array holds" in lib.sa_last_error()
     torch.cuda.synchronize()
+
+
+def test_static_entry_point_allocates_nothing_and_can_be_captured(oracle):
+    """What the entry point is for: device memory in use is the same before and after its calls, and - after
+    sa_align_static_init, outside the capture - a call recorded into a HIP graph gives the eager result on every
+    replay, with the program's own work and synchronisations between the replays."""
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    lib = capi.lib()
+    capi.check(lib.sa_align_static_init(0))
+    q, t = synth.pairs_short_read_window(6000, seed=33)
+    b = align.DeviceAlignBatch(q, t, 1, 1, -1, -1)
+    assert lib.sa_align_may_synchronize(0, C.byref(b.batch), b.workspace_bytes) == 0
+    b.run()
+    want = _outputs(b)
+    b.run_static()      # warm: the kernels' code is resident from here on
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(3):
+        b.run_static()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 == free0
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(graph, stream=side):
+        b.run_static(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    for replay in range(3):
+        for x in (b.d_score, b.d_tb, b.d_runs, b.d_nruns):
+            x.fill_(-1)
+        torch.cuda.synchronize()
+        graph.replay()
+        got = _outputs(b)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g), replay
+        # eager work of the program between the replays
+        other = align.DeviceAlignBatch(q[:500], t[:500], 2, 1, -1, -1)
+        other.run_static()
+        torch.cuda.synchronize()
+    for i in range(0, 6000, 599):
+        assert (int(want[0][i]), b.cigars([i])[0], int(want[1][i])) == oracle.align(bytes(q[i]), bytes(t[i]), 1, 1, -1, -1)
