@@ -1,5 +1,5 @@
 // Device-resident batched MinimizeBinary()/Minimize(): planning, kernels and launches.
-#include "minimizer_kernels.h"
+#include "minimizer_fast.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +38,7 @@ __device__ __forceinline__ uint64_t load8(const uint8_t* p) {  // any alignment
 // The bookkeeping of a call on a single sequence in one launch: chunk and window counts with their (trivial)
 // prefix sums, counters and status cleared.
 __global__ void min_plan_single(const uint64_t* off, uint32_t k, uint32_t w, uint32_t chunk, uint32_t* nchunks,
-                                uint32_t* chunk_base, uint32_t* windows, uint32_t* wbase, uint32_t* counter,
+                                uint32_t* chunk_base, uint32_t* windows, uint32_t* wbase, uint32_t* flags,
                                 int* status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const uint32_t len = (uint32_t)(off[1] - off[0]);
@@ -52,47 +52,171 @@ __global__ void min_plan_single(const uint64_t* off, uint32_t k, uint32_t w, uin
   windows[1] = 0;
   wbase[0] = 0;
   wbase[1] = win;
-  counter[0] = counter[1] = counter[2] = counter[3] = 0;  // keys, unresolved chunks, long sequences, other bytes
+  flags[0] = flags[1] = flags[2] = 0;  // unresolved chunks, long sequences, other bytes
   if (status) *status = 0;
 }
 
-// Writes the keys the lanes of a wave hold in LDS to their sequences' key ranges.  Lanes are ordered by
-// chunk, so lanes of one sequence are neighbours: the first lane of each run reserves the run's total
-// with one atomic on the sequence's counter.  Must be called by all lanes of the wave.
-__device__ __forceinline__ void flush_keys(const MinArgs& a, uint32_t (*bufv)[kThreads],
-                                           uint32_t (*bufp)[kThreads], uint32_t tid, uint32_t seq,
-                                           uint32_t slot, uint32_t& cnt) {
-  const uint32_t lane = tid & 63;
-  uint32_t inc = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t v = __shfl_up(inc, d);
-    if ((int)lane >= d) inc += v;
-  }
-  const uint32_t excl = inc - cnt;
-  const uint32_t total = __shfl(inc, 63);
-  const uint32_t prev = __shfl_up(seq, 1);
-  const bool head = lane == 0 || prev != seq;
-  const uint64_t heads = __ballot(head);
-  const uint32_t leader = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
-  const uint64_t above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-  const uint32_t next = above ? (uint32_t)__builtin_ctzll(above) : 64u;
-  const uint32_t run_begin = __shfl(excl, leader);
-  uint32_t run_end = __shfl(excl, next & 63);
-  if (next == 64) run_end = total;
-  uint32_t base = 0;
-  if (head && run_end > run_begin) base = atomicAdd(&a.counter[seq], run_end - run_begin);
-  base = __shfl(base, leader);
-  uint64_t* dst = a.keys + slot + base + (excl - run_begin);
-  for (int i = 0; i < kBuf; ++i) {
-    if (!__any((uint32_t)i < cnt)) break;
-    if ((uint32_t)i < cnt) {
-      const uint64_t key = ((uint64_t)bufv[i][tid] << a.key_shift) | bufp[i][tid];
-      dst[i] = key;
-      if (a.hist) atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u);
+// ---- key output ---------------------------------------------------------------------------------
+// Every chunk owns the key slots of its own windows: chunk c of sequence s writes its keys (at most one per
+// window, adjacent repeats dropped) from keys[wbase[s] + first_window] on and leaves their number in
+// chunk_count[c].  No lane ever writes into another lane's range, so the output needs no atomics and no
+// scan; the consumers (sort_emit_small for reads, bucket_scatter for one long sequence, compact_keys for the
+// rest) walk a sequence's chunks.  What is stored is the RAW key: value in the low word, position << 1 |
+// strand in the high word (compose_key shifts them together); lanes collect raw keys in LDS (kBuf slots each)
+// and the wave writes them out together, 16 lanes per source lane and 16 bytes per lane, so that a store
+// instruction covers four lanes' runs of up to 256 contiguous bytes instead of 64 scattered keys.
+constexpr int kBuf = 24;
+constexpr uint32_t kFlushAt = kBuf - 9;  // a check every 8 steps: flush when some lane holds more keys than this
+static_assert(kBuf <= 32 && kBuf % 2 == 0, "one pass of flush_keys covers 32 keys per lane");
+
+__device__ __forceinline__ uint64_t compose_key(uint64_t raw, uint32_t key_shift) {
+  return ((uint64_t)(uint32_t)raw << key_shift) | (raw >> 32);
+}
+
+struct KeyOut {
+  uint64_t* dst;     // the chunk's first key slot
+  uint32_t written;  // keys written so far
+  uint32_t cnt;      // keys waiting in LDS
+  bool ok;           // false: the lane's keys are dropped (no chunk, or a chunk left to min_fix)
+};
+
+struct FlushHeader {  // what a lane tells the lanes that copy its keys
+  uint64_t* to;
+  uint32_t cnt, pad;
+};
+
+// Writes the lanes' buffered entries (x: value << SHIFT | tag bits below, y: position << 1 | strand).  Called by
+// all lanes of a wave.
+template <uint32_t SHIFT>
+__device__ __forceinline__ void flush_keys(const MinArgs& a, uint2 (*buf)[kThreads], FlushHeader* hdr, uint32_t tid,
+                                           KeyOut& o) {
+  const uint32_t lane = tid & 63, team = lane >> 4, idx = lane & 15;
+  FlushHeader mine;
+  mine.to = o.dst + o.written;
+  mine.cnt = o.ok ? o.cnt : 0;
+  mine.pad = 0;
+  hdr[tid] = mine;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS accesses of one wave execute in program order)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+  for (uint32_t g = 0; g < 16; ++g) {
+    const uint32_t src = (tid - lane) + g * 4 + team;
+    const FlushHeader h = hdr[src];
+    uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
+    if (2 * idx < (uint32_t)kBuf) {
+      e0 = buf[2 * idx][src];
+      e1 = buf[2 * idx + 1][src];
+    }
+    e0.x >>= SHIFT;
+    e1.x >>= SHIFT;
+    if (2 * idx + 1 < h.cnt) {
+      *reinterpret_cast<uint4*>(h.to + 2 * idx) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+    } else if (2 * idx < h.cnt) {
+      *reinterpret_cast<uint2*>(h.to + 2 * idx) = e0;
+    }
+    if (a.hist) {  // (calls on one sequence) the bucketed sort's histogram
+      if (2 * idx < h.cnt)
+        atomicAdd(&a.hist[fine_slot((uint32_t)(compose_key(((uint64_t)e0.y << 32) | e0.x, a.key_shift) >> a.fine_shift))], 1u);
+      if (2 * idx + 1 < h.cnt)
+        atomicAdd(&a.hist[fine_slot((uint32_t)(compose_key(((uint64_t)e1.y << 32) | e1.x, a.key_shift) >> a.fine_shift))], 1u);
     }
   }
-  cnt = 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (o.ok) o.written += o.cnt;
+  o.cnt = 0;
+}
+
+// 16 bytes from p, any alignment; bytes at or beyond `end` read as 0 (the slow branch is taken by the last
+// lanes of the last sequence only)
+__device__ __forceinline__ uint4 load16_guard(const uint8_t* p, const uint8_t* end) {
+  if (p + 16 <= end) return *reinterpret_cast<const uint4*>(p);
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // byte by byte, last byte first: a 128-bit shift register
+#pragma nounroll
+  for (int x = 15; x >= 0; --x) {
+    const uint32_t byte = (p + x < end) ? (uint32_t)p[x] : 0u;
+    w0 = (w0 << 8) | (w1 >> 24);
+    w1 = (w1 << 8) | (w2 >> 24);
+    w2 = (w2 << 8) | (w3 >> 24);
+    w3 = (w3 << 8) | byte;
+  }
+  return make_uint4(w3, w2, w1, w0);  // byte 0 ended in the low byte of w3
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// The steps r0 .. r0 + 15 of Fast5 on the 16 bytes `bytes`.
+//   MODE 0: windows before every lane's chunk - nothing is emitted
+//   MODE 1: every lane emits
+//   MODE 2: lanes emit while lo <= r < hi; a lane's state after its last window is kept in ex_pf / ex_pc
+template <int MODE, class FM, class M>
+__device__ __forceinline__ void fast_block16(FM& fm, uint32_t r0, const uint4& bytes, uint32_t& other, uint2 (*buf)[kThreads],
+                                             FlushHeader* hdr, uint32_t tid, KeyOut& o, uint32_t lo, uint32_t hi,
+                                             uint32_t& ex_pf, uint32_t& ex_pc, const MinArgs& a, uint32_t j0) {
+  constexpr uint32_t S = FM::S;
+  const uint32_t base2 = 2u * (j0 + r0);  // stored positions are positions in the sequence
+  constexpr uint32_t kSlotBytes = kThreads * 8u;
+  uint32_t slot = o.cnt * kSlotBytes + tid * 8u;  // byte offset of buf[o.cnt][tid]
+  // Bytes other than bases count as evidence only where they belong to the lane's own windows: the steps run
+  // on for lanes whose chunk has ended (and for lanes without a chunk), over bytes of the next sequence or of
+  // the slack behind the blob.
+  uint32_t cw[4], oth = 0;
+  cw[0] = M::feed4(bytes.x, oth);
+  cw[1] = M::feed4(bytes.y, oth);
+  cw[2] = M::feed4(bytes.z, oth);
+  cw[3] = M::feed4(bytes.w, oth);
+  if (r0 + 16 <= hi) {
+    other |= oth;
+  } else if (r0 < hi) {
+    const uint32_t ws[4] = {bytes.x, bytes.y, bytes.z, bytes.w};
+    for (uint32_t x = 0; x < hi - r0; ++x) other |= other1((ws[x >> 2] >> (8 * (x & 3))) & 0xFFu);
+  }
+  if (S <= 6) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) cw[x] <<= S;
+  }
+  auto one = [&](auto u_tag) __attribute__((always_inline)) {
+    constexpr uint32_t U = decltype(u_tag)::value;
+    const uint32_t r = r0 + U;
+    uint32_t cs;
+    if (S <= 6)
+      cs = (cw[U >> 2] >> (8 * (U & 3))) & ((4u << S) - 1u);  // (the S bits below the code are zero)
+    else
+      cs = ((cw[U >> 2] >> (8 * (U & 3))) & 3u) << S;
+    uint32_t word, p2;
+    const bool fresh = fm.template step<U, MODE != 0>(cs, &word, &p2);
+    // every window's tuple goes to the lane's next free slot; the slot only moves on when the tuple is new
+    if (MODE != 0) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(&buf[0][0]) + slot) = make_uint2(word, p2 + base2);
+    if (MODE == 1) {
+      slot += fresh ? kSlotBytes : 0u;
+    } else if (MODE == 2) {
+      slot += (fresh && (r - lo) < (hi - lo)) ? kSlotBytes : 0u;
+      const bool last = r + 1 == hi;
+      ex_pf = last ? fm.pf + r0 : ex_pf;
+      ex_pc = last ? fm.pc + r0 : ex_pc;
+    }
+    if (MODE != 0 && (U & 7) == 7) {
+      o.cnt = (slot - tid * 8u) / kSlotBytes;
+      if (__any(o.cnt > kFlushAt)) {
+        flush_keys<S>(a, buf, hdr, tid, o);
+        slot = tid * 8u;
+      }
+    }
+  };
+#define SA_FAST_STEP(X) one(std::integral_constant<uint32_t, X>{});
+  SA_FAST_STEP(0) SA_FAST_STEP(1) SA_FAST_STEP(2) SA_FAST_STEP(3) SA_FAST_STEP(4) SA_FAST_STEP(5) SA_FAST_STEP(6)
+  SA_FAST_STEP(7) SA_FAST_STEP(8) SA_FAST_STEP(9) SA_FAST_STEP(10) SA_FAST_STEP(11) SA_FAST_STEP(12) SA_FAST_STEP(13)
+  SA_FAST_STEP(14) SA_FAST_STEP(15)
+#undef SA_FAST_STEP
+  if (MODE != 0) o.cnt = (slot - tid * 8u) / kSlotBytes;
+  fm.rebase();
 }
 
 // One thread per chunk: proves the chunk's entry state (exactly from the sequence start, or by collapsing
@@ -100,10 +224,12 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint32_t (*bufv)[kT
 // duplicates dropped.
 // M = Machine<W>: the fast machine, exact as long as every byte is a base - it reports other bytes in
 // a.other.  M = MachineX: the exact machine for such batches; returns at once unless a.other is set.
-template <class M>
+// FASTK != 0 (with M = Machine<5>, k = FASTK): once the entry state is known the windows run on Fast5<FASTK>,
+// all lanes of a wave in step.
+template <class M, uint32_t FASTK>
 __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unresolved) {
-  __shared__ uint32_t bufv[kBuf][kThreads];  // buffered tuples: value
-  __shared__ uint32_t bufp[kBuf][kThreads];  //                  position << 1 | strand
+  __shared__ uint2 buf[kBuf][kThreads];  // buffered tuples
+  __shared__ FlushHeader hdr[kThreads];
   if (M::kExact && *a.other == 0) return;
   uint32_t other = 0;
   const uint32_t tid = threadIdx.x;
@@ -111,22 +237,23 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   ChunkRef c;
   const bool valid = locate_chunk(a, chunk, &c);
   const uint8_t* s = a.seq + (valid ? c.base : 0);
+  const uint8_t* blob_end = a.seq + a.off[a.n] + 8;  // the blob is readable 8 bytes past its last sequence
   const uint32_t F = valid ? c.first_window : 0, E = valid ? c.end_window : 0;
-  const uint32_t seq = valid ? c.seq : 0xFFFFFFFFu;
-  const uint32_t slot = valid ? a.wbase[c.seq] : 0;
   const uint32_t k = a.k, w = a.w;
+  KeyOut o;
+  o.dst = a.keys + (valid ? (uint64_t)a.wbase[c.seq] + F : 0);
+  o.written = o.cnt = 0;
+  o.ok = valid;
   M m;
   m.reset(k, w);
   uint32_t i = E;  // next window
-  uint32_t cnt = 0;
   uint32_t lastv = 0, lastp = ~0u;  // the tuple written last (no real tuple has position bits ~0)
   auto emit = [&]() __attribute__((always_inline)) {
     uint32_t v, p2;
     m.tuple(&v, &p2);
     if (v != lastv || p2 != lastp) {
-      bufv[cnt][tid] = v;
-      bufp[cnt][tid] = p2;
-      ++cnt;
+      buf[o.cnt][tid] = make_uint2(v, p2);
+      ++o.cnt;
       lastv = v;
       lastp = p2;
     }
@@ -164,70 +291,130 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
     else
       live = false;  // left to min_fix
   }
-  // single steps until the windows left before the chunk are a multiple of 8: a group of 8 steps below
-  // then lies entirely before the chunk (nothing to emit) or entirely inside it
-  {
-    const uint32_t align = (live && i < F) ? ((F - i) & 7u) : 0;
-    const uint32_t max_align = wave_max_u32(align);
-    for (uint32_t u = 0; u < max_align; ++u) {
-      if (u < align) {
-        m.step(M::feed1(s[m.j + k - 1], other));
-        ++i;
-      }
+  o.ok = live;
+  if (i > E) i = E;  // (a one-window chunk at the sequence start)
+  uint32_t exit_pf = m.pf, exit_pc = m.pc;
+  if constexpr (FASTK != 0) {
+    // Every lane's next window is i (its step r handles window i + r); lanes emit for lo <= r < hi.
+    using FM = Fast5<(FASTK ? FASTK : 15)>;
+    const uint32_t j0 = m.j;
+    const uint32_t lo = live ? (F > i ? F - i : 0u) : 0u, hi = live ? E - i : 0u;
+    if (__any(o.cnt > 0)) flush_keys<0>(a, buf, hdr, tid, o);
+    FM fm;
+    fm.enter(m, j0, lastp);
+    const uint32_t lo_min = __builtin_amdgcn_readfirstlane(wave_min_u32(live ? lo : ~0u));
+    const uint32_t lo_max = __builtin_amdgcn_readfirstlane(wave_max_u32(live ? lo : 0u));
+    const uint32_t hi_min = __builtin_amdgcn_readfirstlane(wave_min_u32(live ? hi : ~0u));
+    const uint32_t hi_max = __builtin_amdgcn_readfirstlane(wave_max_u32(live ? hi : 0u));
+    const uint32_t end_all = (hi_max + 15u) & ~15u;                       // 0 when no lane is live
+    const uint32_t end_a = lo_min == ~0u ? 0u : (lo_min & ~15u);          // [0, end_a): before every chunk
+    uint32_t end_b = (lo_max + 15u) & ~15u;                               // [end_a, end_b): some lanes emit
+    uint32_t end_c = hi_min == ~0u ? 0u : (hi_min & ~15u);                // [end_b, end_c): all lanes emit
+    if (end_b > end_all) end_b = end_all;
+    if (end_c < end_b) end_c = end_b;
+    if (end_c > end_all) end_c = end_all;
+    const uint8_t* bp = s + (j0 + FM::kK - 1);  // the base step r consumes is bp[r]
+    uint32_t ex_pf = fm.pf, ex_pc = fm.pc;
+    uint4 cur = load16_guard(bp, blob_end);
+    uint32_t r0 = 0;
+    for (; r0 < end_a; r0 += 16) {
+      const uint4 nxt = load16_guard(bp + r0 + 16, blob_end);
+      fast_block16<0, FM, M>(fm, r0, cur, other, buf, hdr, tid, o, lo, hi, ex_pf, ex_pc, a, j0);
+      cur = nxt;
     }
-  }
-  const uint32_t rem = live ? E - i : 0;
-  const uint32_t groups = rem >> 3, tail = rem & 7;
-  const uint32_t max_groups = wave_max_u32(groups), max_tail = wave_max_u32(tail);
-  const uint8_t* next_base = s + (m.j + k - 1);
-  uint64_t word = rem ? load8(next_base) : 0;
-  for (uint32_t g = 0; g < max_groups; ++g) {
-    if (g < groups) {
-      const uint32_t c0 = M::feed4((uint32_t)word, other), c1 = M::feed4((uint32_t)(word >> 32), other);
-      next_base += 8;
-      if (g + 1 < groups || tail) word = load8(next_base);
-      if (i >= F) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & M::kFeedMask);
-          emit();
+    if (end_a) fm.lastp = FM::kNoTuple;  // (the steps above do not keep it)
+    for (; r0 < end_b; r0 += 16) {
+      const uint4 nxt = load16_guard(bp + r0 + 16, blob_end);
+      fast_block16<2, FM, M>(fm, r0, cur, other, buf, hdr, tid, o, lo, hi, ex_pf, ex_pc, a, j0);
+      cur = nxt;
+    }
+    for (; r0 < end_c; r0 += 16) {
+      const uint4 nxt = load16_guard(bp + r0 + 16, blob_end);
+      fast_block16<1, FM, M>(fm, r0, cur, other, buf, hdr, tid, o, lo, hi, ex_pf, ex_pc, a, j0);
+      cur = nxt;
+    }
+    if (hi == r0) {  // the lane's last window was the last step of the stretch in which every lane emits
+      ex_pf = fm.pf + r0;
+      ex_pc = fm.pc + r0;
+    }
+    for (; r0 < end_all; r0 += 16) {
+      const uint4 nxt = load16_guard(bp + r0 + 16, blob_end);
+      fast_block16<2, FM, M>(fm, r0, cur, other, buf, hdr, tid, o, lo, hi, ex_pf, ex_pc, a, j0);
+      cur = nxt;
+    }
+    if (__any(o.cnt > 0)) flush_keys<FM::S>(a, buf, hdr, tid, o);
+    exit_pf = ex_pf + j0;
+    exit_pc = ex_pc + j0;
+  } else {
+    // single steps until the windows left before the chunk are a multiple of 8: a group of 8 steps below
+    // then lies entirely before the chunk (nothing to emit) or entirely inside it
+    {
+      const uint32_t align = (live && i < F) ? ((F - i) & 7u) : 0;
+      const uint32_t max_align = wave_max_u32(align);
+      for (uint32_t u = 0; u < max_align; ++u) {
+        if (u < align) {
+          m.step(M::feed1(s[m.j + k - 1], other));
+          ++i;
         }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & M::kFeedMask);
       }
-      i += 8;
     }
-    if (__any(cnt > (uint32_t)(kBuf - 8))) flush_keys(a, bufv, bufp, tid, seq, slot, cnt);
-  }
-  for (uint32_t u = 0; u < max_tail; ++u) {
-    if (u < tail) {
-      m.step(M::feed1((uint32_t)(word >> (8 * u)) & 0xFFu, other));
-      emit();
+    const uint32_t rem = live ? E - i : 0;
+    const uint32_t groups = rem >> 3, tail = rem & 7;
+    const uint32_t max_groups = wave_max_u32(groups), max_tail = wave_max_u32(tail);
+    const uint8_t* next_base = s + (m.j + k - 1);
+    uint64_t word = rem ? load8(next_base) : 0;
+    for (uint32_t g = 0; g < max_groups; ++g) {
+      if (g < groups) {
+        const uint32_t c0 = M::feed4((uint32_t)word, other), c1 = M::feed4((uint32_t)(word >> 32), other);
+        next_base += 8;
+        if (g + 1 < groups || tail) word = load8(next_base);
+        if (i >= F) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & M::kFeedMask);
+            emit();
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) m.step(((u < 4 ? c0 : c1) >> (8 * (u & 3))) & M::kFeedMask);
+        }
+        i += 8;
+      }
+      if (__any(o.cnt > (uint32_t)(kBuf - 8))) flush_keys<0>(a, buf, hdr, tid, o);
     }
+    for (uint32_t u = 0; u < max_tail; ++u) {
+      if (u < tail) {
+        m.step(M::feed1((uint32_t)(word >> (8 * u)) & 0xFFu, other));
+        emit();
+      }
+    }
+    if (__any(o.cnt > 0)) flush_keys<0>(a, buf, hdr, tid, o);
+    exit_pf = m.pf;
+    exit_pc = m.pc;
   }
-  if (__any(cnt > 0)) flush_keys(a, bufv, bufp, tid, seq, slot, cnt);
   if (valid) {
-    a.exit_f[chunk] = m.pf;
-    a.exit_c[chunk] = m.pc;
+    a.chunk_count[chunk] = o.written;
+    a.exit_f[chunk] = exit_pf;
+    a.exit_c[chunk] = exit_pc;
     a.resolved[chunk] = live ? 1 : 0;
     if (!live) atomicAdd(n_unresolved, 1u);
   }
   if (!M::kExact && other) atomicOr(a.other, 1u);
 }
 
-// Before the exact machine runs a batch again: forget the keys and the unresolved chunks of the first run.
-__global__ void min_redo_reset(uint32_t* counter, uint32_t n, const uint32_t* other, uint32_t* hist,
-                               uint32_t hist_words) {
+// Before the exact machine runs a batch again: forget the unresolved chunks and the histogram of the first
+// run (every chunk writes its keys and their number again).
+__global__ void min_redo_reset(uint32_t* n_unresolved, const uint32_t* other, uint32_t* hist, uint32_t hist_words) {
   if (*other == 0) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= n) counter[i] = 0;  // n counters and the count of unresolved chunks behind them
-  if (hist)                    // (single-sequence calls) the keys counted so far
+  if (i == 0) *n_unresolved = 0;
+  if (hist)  // (single-sequence calls) the keys counted so far
     for (uint32_t x = i; x < hist_words; x += gridDim.x * blockDim.x) hist[x] = 0;
 }
 
 // One wave per sequence, only when some chunk's candidate set did not collapse: those chunks take their
-// entry state from the (final) exit state of the chunk before them, in order.  Lane 0 runs the machine.
+// entry state from the (final) exit state of the chunk before them, in order, and write their keys anew.
+// Lane 0 runs the machine.
 template <class M>
 __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n_unresolved) {
   if (*n_unresolved == 0) return;
@@ -239,7 +426,6 @@ __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n
   const uint8_t* seq = a.seq + a.off[s];
   const uint32_t windows = (uint32_t)(a.off[s + 1] - a.off[s]) - a.w - a.k + 2;
   const uint32_t k = a.k, w = a.w;
-  uint64_t* out = a.keys + a.wbase[s];
   for (uint32_t c0 = c_begin; c0 < c_end; c0 += 64) {
     const uint32_t mine = c0 + lane;
     uint64_t todo = __ballot(mine < c_end && !a.resolved[mine]);
@@ -249,24 +435,27 @@ __global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n
       if (lane == 0) {
         const uint32_t F = (chunk - c_begin) * a.chunk;
         const uint32_t E = F + a.chunk < windows ? F + a.chunk : windows;
+        uint64_t* out = a.keys + (uint64_t)a.wbase[s] + F;
         M m;
         uint32_t other = 0;  // the run kernel has looked at every byte already
         m.reset(k, w);
         const uint32_t j = F + w - 1;
         for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(M::feed1(seq[b], other));
         m.enter(j, a.exit_f[chunk - 1], a.exit_c[chunk - 1]);
-        uint32_t n_out = a.counter[s];
+        uint32_t n_out = 0;
         uint64_t last = ~0ull;
         for (uint32_t i = F; i < E; ++i) {
           m.step(M::feed1(seq[m.j + k - 1], other));
-          const uint64_t key = m.key(a.key_shift);
-          if (key != last) {
-            out[n_out++] = key;
-            if (a.hist) atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u);
-            last = key;
+          uint32_t v, p2;
+          m.tuple(&v, &p2);
+          const uint64_t raw = ((uint64_t)p2 << 32) | v;
+          if (raw != last) {
+            out[n_out++] = raw;
+            if (a.hist) atomicAdd(&a.hist[fine_slot((uint32_t)(compose_key(raw, a.key_shift) >> a.fine_shift))], 1u);
+            last = raw;
           }
         }
-        a.counter[s] = n_out;
+        a.chunk_count[chunk] = n_out;
         a.exit_f[chunk] = m.pf;
         a.exit_c[chunk] = m.pc;
         a.resolved[chunk] = 1;
@@ -321,8 +510,8 @@ __device__ uint32_t run_decimal(const MinArgs& a, uint32_t s, uint64_t* out, boo
   uint32_t n_out = 0;
   uint64_t last = ~0ull;
   auto emit = [&](int fmin, int fidx, int cmin, int cidx) {
-    const uint64_t key = (fmin < cmin) ? make_key((uint32_t)fmin, (uint32_t)fidx, 1, a.key_shift)
-                                       : make_key((uint32_t)cmin, (uint32_t)cidx, 0, a.key_shift);
+    const uint64_t key = (fmin < cmin) ? (((uint64_t)((uint32_t)fidx << 1 | 1u) << 32) | (uint32_t)fmin)
+                                       : (((uint64_t)((uint32_t)cidx << 1) << 32) | (uint32_t)cmin);  // raw
     if (key != last) {
       if (WRITE) out[n_out] = key;
       ++n_out;
@@ -369,29 +558,57 @@ __global__ __launch_bounds__(kThreads) void dec_run(MinArgs a) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.n) return;
   bool bad = false;
-  a.counter[s] = run_decimal<true>(a, s, a.keys + a.wbase[s], &bad);
+  a.chunk_count[a.chunk_base[s]] = run_decimal<true>(a, s, a.keys + a.wbase[s], &bad);  // one chunk per sequence
   if (bad && a.status) atomicMax(a.status, SA_ERR_RANGE);
 }
 
 // ---- sort / unique / output ---------------------------------------------------------------------
-// Sequence s's keys are [wbase[s], wbase[s] + counter[s]) of the key array; the unique pass walks them
-// in tiles of kTile keys.
+// The sort and unique kernels want a sequence's keys in one piece: compact_keys moves every chunk's keys to
+// cscan[chunk] (the exclusive scan of the chunks' key counts) of a second array, where sequence s then owns
+// [cscan[chunk_base[s]], cscan[chunk_base[s + 1]]).  Batches of reads skip this (sort_emit_small collects a
+// read's chunks itself): with skip_unless_big set the kernel returns at once unless some sequence has more
+// than kTile keys.
+__global__ __launch_bounds__(kThreads) void compact_keys(MinArgs a, const uint32_t* cscan, uint64_t* dst,
+                                                         const uint32_t* skip_unless_big) {
+  if (skip_unless_big && *skip_unless_big == 0) return;
+  const uint32_t nchunks = a.chunk_base[a.n];
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    ChunkRef c;
+    locate_chunk(a, chunk, &c);
+    const uint64_t* src = a.keys + (uint64_t)a.wbase[c.seq] + c.first_window;
+    const uint32_t count = a.chunk_count[chunk], to = cscan[chunk];
+    for (uint32_t x = threadIdx.x; x < count; x += kThreads) dst[to + x] = compose_key(src[x], a.key_shift);
+  }
+}
+
+// Reads: a sequence's number of keys from its (few) chunks, and the number of sequences with more than
+// kTile keys, which decides between sort_emit_small and the several-kernel path.
+__global__ void min_count_direct(MinArgs a, uint32_t* seq_count, uint32_t* n_big) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n) return;
+  uint32_t c = 0;
+  for (uint32_t x = a.chunk_base[s]; x < a.chunk_base[s + 1]; ++x) c += a.chunk_count[x];
+  seq_count[s] = c;
+  if (c > kTile) atomicAdd(n_big, 1u);
+}
+
 // big_end / n_big: sequences with more than kTile keys are "big" - they are left to the segmented radix sort,
 // whose segment s is [seg_begin[s], big_end[s]) (empty for the others, which are sorted inside LDS).
-__global__ void min_segments(const uint32_t* wbase, const uint32_t* counter, uint32_t n,
+// count_big = 0: n_big has been counted already (min_count_direct).
+__global__ void min_segments(const uint32_t* cscan, const uint32_t* chunk_base, uint32_t n,
                              uint32_t* seg_begin, uint32_t* seg_end, uint32_t* big_end, uint32_t* tiles,
-                             uint32_t* n_big) {
+                             uint32_t* n_big, uint32_t count_big) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > n) return;
   if (s == n) {
     tiles[s] = 0;
     return;
   }
-  const uint32_t c = counter[s];
-  seg_begin[s] = wbase[s];
-  seg_end[s] = wbase[s] + c;
-  big_end[s] = c > kTile ? wbase[s] + c : wbase[s];
-  if (c > kTile) atomicAdd(n_big, 1u);
+  const uint32_t first = cscan[chunk_base[s]], c = cscan[chunk_base[s + 1]] - first;
+  seg_begin[s] = first;
+  seg_end[s] = first + c;
+  big_end[s] = c > kTile ? first + c : first;
+  if (count_big && c > kTile) atomicAdd(n_big, 1u);
   tiles[s] = (c + kTile - 1) / kTile;
 }
 
@@ -595,7 +812,16 @@ struct EmitArgs {
   const uint32_t* seg_hif;
   const uint64_t* seg_lokey;  // set by bucket_split for the slices of an oversized bucket (seg_hif == 0 there)
   const uint64_t* seg_span;
+  // direct != 0 (reads): sequence s's keys lie where its chunks wrote them - chunk c's chunk_count[c] keys from
+  // keys[wbase[s] + (c - chunk_base[s]) * chunk] on, at most kDirectChunks chunks per sequence - and seg_begin
+  // holds the sequences' key counts
+  uint32_t direct;
+  const uint32_t* chunk_base;
+  const uint32_t* chunk_count;
+  const uint32_t* wbase;
+  uint32_t chunk;
 };
+constexpr uint32_t kDirectChunks = 32;
 
 __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   // one buffer, two uses: [0, 4096) grouped keys + [4096, 5120) bin counters (16 bits each, two per dword)
@@ -626,8 +852,29 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   const uint32_t s = s_seq;
   const uint32_t nsegs = a.buckets ? *a.nseg_used : a.n;
   if (s >= nsegs) return;
-  const uint32_t begin = a.seg_begin[s];
-  uint32_t count = a.seg_end[s] - begin;  // <= kSmallMax: n_big == 0, bucket_split
+  __shared__ uint32_t cpre[kDirectChunks + 1];  // direct: exclusive prefix of the sequence's chunk counts
+  const uint32_t begin = a.direct ? a.wbase[s] : a.seg_begin[s];
+  uint32_t count = a.direct ? a.seg_begin[s] : a.seg_end[s] - begin;  // <= kSmallMax: n_big == 0, bucket_split
+  uint32_t nch = 0;
+  if (a.direct) {
+    const uint32_t c0 = a.chunk_base[s];
+    nch = a.chunk_base[s + 1] - c0;  // <= kDirectChunks (the host checks the bound)
+    if (tid == 0) {
+      uint32_t sum = 0;
+      for (uint32_t x = 0; x < nch; ++x) {
+        cpre[x] = sum;
+        sum += a.chunk_count[c0 + x];
+      }
+      cpre[nch] = sum;
+    }
+    __syncthreads();
+  }
+  uint32_t ch = 0;  // direct: the chunk of the key loaded last (a thread's keys come in increasing order)
+  auto load_key = [&](uint32_t i) -> uint64_t {  // key i of the sequence
+    if (!a.direct) return a.keys[begin + i];
+    while (ch + 1 < nch && cpre[ch + 1] <= i) ++ch;
+    return compose_key(a.keys[(uint64_t)begin + (uint64_t)ch * a.chunk + (i - cpre[ch])], a.key_shift);
+  };
   if (count > kSmallMax) {                // never expected: fail the call rather than overrun the buffers
     if (tid == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
     count = kSmallMax;
@@ -662,7 +909,7 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   for (uint32_t e = 0; e < kPer; ++e) {
     const uint32_t i = tid + e * kThreads;
     if (i < count) {
-      mine[e] = a.keys[begin + i];
+      mine[e] = load_key(i);
       bin[e] = bin_of(mine[e]);
       bin_inc(bin[e]);
     }
@@ -895,12 +1142,15 @@ constexpr uint32_t kBucketShift = 10, kBucketKeys = 1u << kBucketShift;
 constexpr uint32_t kNoBin = 0xFFFFFFFFu;
 
 struct BucketArgs {
-  const uint64_t* keys;     // the sequence's keys as min_run left them
+  const uint64_t* keys;     // the sequence's keys as min_run left them: chunk c's from slot c * chunk on
   uint64_t* grouped;        // the same keys, grouped by fine bin
-  const uint32_t* count;    // number of keys (device side)
+  const uint32_t* nchunks;  // chunks of the sequence (device side)
+  const uint32_t* chunk_count;
+  uint32_t chunk;
   uint32_t fine_shift;
   uint32_t* hist;           // kFine counters, zeroed; after bucket_plan: exclusive prefix / cursors
   uint32_t nseg;            // bucket numbers 0 .. nseg - 1 (more than the keys can fill)
+  uint32_t key_shift;       // (the chunks hold raw keys)
   uint32_t* nseg_used;      // bucket numbers the keys of this call reach: (count >> kBucketShift) + 1
   uint32_t* seg_begin;      // all zeroed before bucket_plan
   uint32_t* seg_end;
@@ -977,11 +1227,17 @@ __global__ __launch_bounds__(kThreads) void bucket_plan(BucketArgs a) {
   if (tid == 0) *a.nseg_used = (total >> kBucketShift) + 1;
 }
 
+// (one wave per chunk of the sequence: chunk c's keys start at key slot c * chunk)
 __global__ __launch_bounds__(kThreads) void bucket_scatter(BucketArgs a) {
-  const uint32_t n = *a.count;
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    const uint64_t key = a.keys[i];
-    a.grouped[atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u)] = key;
+  const uint32_t nchunks = *a.nchunks, lane = threadIdx.x & 63;
+  const uint32_t waves = gridDim.x * (kThreads / 64);
+  for (uint32_t c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); c < nchunks; c += waves) {
+    const uint32_t n = a.chunk_count[c];
+    const uint64_t* src = a.keys + (uint64_t)c * a.chunk;
+    for (uint32_t i = lane; i < n; i += 64) {
+      const uint64_t key = compose_key(src[i], a.key_shift);
+      a.grouped[atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u)] = key;
+    }
   }
 }
 
@@ -1106,8 +1362,11 @@ struct MinPlan {
   size_t scan32_tmp, scan64_tmp, sort_tmp;
   size_t total_bytes;
   // workspace offsets
-  size_t o_nchunks, o_chunk_base, o_windows, o_wbase, o_counter, o_exit_f, o_exit_c, o_resolved, o_keys,
-      o_sorted, o_seg_begin, o_seg_end, o_big_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_scan_state, o_tmp;
+  size_t o_nchunks, o_chunk_base, o_windows, o_wbase, o_flags, o_chunk_count, o_cscan, o_exit_f, o_exit_c, o_resolved,
+      o_keys, o_sorted, o_seg_begin, o_seg_end, o_big_end, o_tiles, o_tile_base, o_tile_count, o_tile_off, o_scan_state,
+      o_tmp;
+  size_t scan_chunks_tmp;
+  bool direct;          // reads: at most kDirectChunks chunks per sequence, sort_emit_small collects them itself
   // one sequence of moderate length: bucketed sort (bucket_plan)
   bool buckets;
   uint32_t nseg, fine_shift;
@@ -1136,18 +1395,28 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   const uint64_t span = (uint64_t)k + w - 2;
   pl->capacity = total_len > span * n ? total_len - span * n : 1;  // total windows
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
-  // enough chunks to occupy the GPU: 1024 or 2048 windows each for large batches (a chunk pays 160 warm-up
-  // steps; measured on 1 Gbp of reads: 4.50 ms with 1024, 4.29 with 2048, 4.73 with 4096), 256 or 128 for
-  // small ones (one 4.6 Mbp sequence: 130 / 119 / 102 / 125 / 172 us with 32 / 64 / 128 / 256 / 512)
+  // enough chunks to occupy the GPU: about 2048 windows each for large batches (a chunk pays 160 warm-up
+  // steps), 256 or 128 for small ones (one 4.6 Mbp sequence: 130 / 119 / 102 / 125 / 172 us with 32 / 64 / 128 /
+  // 256 / 512)
   pl->chunk = (total_len / 2048 >= 65536)  ? 2048
               : (total_len / 1024 >= 65536) ? 1024
               : (total_len / 256 >= 65536)  ? 256
                                             : 128;
+  const uint64_t max_windows = max_len > span ? max_len - span : 1;
+  // sequences of about one length (reads): equal chunks - the lanes of a wave run in step, a short last chunk
+  // idles its lane
+  if (n > 1 && pl->chunk >= 1024 && max_windows > pl->chunk && pl->capacity >= (uint64_t)n * max_windows / 16 * 15) {
+    const uint64_t per_seq = (max_windows + pl->chunk - 1) / pl->chunk;
+    pl->chunk = (uint32_t)(((max_windows + per_seq - 1) / per_seq + 15) / 16 * 16);
+  }
   {  // test hook: any chunk length from 8 to 4096 windows
     const long v = options().min_chunk;
     if (v >= 8 && v <= 4096) pl->chunk = (uint32_t)v;
   }
+  if (variant == SA_MIN_DECIMAL)  // one thread per sequence: one chunk per sequence
+    pl->chunk = (uint32_t)std::min<uint64_t>((max_windows + 15) / 16 * 16, 0xFFFFFFF0u);
   pl->max_chunks = (uint32_t)(total_len / pl->chunk + n);
+  pl->direct = n > 1 && (max_windows + pl->chunk - 1) / pl->chunk <= kDirectChunks;
   pl->max_tiles = (uint32_t)(pl->capacity / kTile + n);
   // w = 1 can emit k-mer 0, whose value the reference builds without the mask: with a non-base byte in it
   // the value has ones above its 2k bits
@@ -1163,6 +1432,8 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->scan32_tmp = pl->scan64_tmp = pl->sort_tmp = 0;
   if (rocprim::exclusive_scan(nullptr, pl->scan32_tmp, d32, d32, 0u, (size_t)n + 1, rocprim::plus<uint32_t>()) != hipSuccess) return SA_ERR_HIP;
   if (rocprim::exclusive_scan(nullptr, pl->scan64_tmp, d32, d64, (uint64_t)0, mt, rocprim::plus<uint64_t>()) != hipSuccess) return SA_ERR_HIP;
+  pl->scan_chunks_tmp = 0;
+  if (rocprim::exclusive_scan(nullptr, pl->scan_chunks_tmp, d32, d32, 0u, mc, rocprim::plus<uint32_t>()) != hipSuccess) return SA_ERR_HIP;
   if (n == 1) {
     if (rocprim::radix_sort_keys(nullptr, pl->sort_tmp, d64, d64, (size_t)pl->capacity, 0u, pl->end_bit) != hipSuccess) return SA_ERR_HIP;
   } else {
@@ -1179,7 +1450,9 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->o_chunk_base = take(n1);
   pl->o_windows = take(n1);
   pl->o_wbase = take(n1);
-  pl->o_counter = take(n1 + 8);  // n counters, unresolved chunks, long sequences, "bytes other than bases seen"
+  pl->o_flags = take(16);        // unresolved chunks, long sequences, "bytes other than bases seen"
+  pl->o_chunk_count = take(mc * 4);
+  pl->o_cscan = take(mc * 4);
   pl->o_exit_f = take(mc * 4);
   pl->o_exit_c = take(mc * 4);
   pl->o_resolved = take(mc);
@@ -1209,7 +1482,7 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
     pl->o_bscan = take((ns + 2) * 8);  // scan state, ticket, buckets in use
     pl->bucket_zero_bytes = o - pl->o_bucket_zero;
   }
-  pl->o_tmp = take(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), pl->sort_tmp));
+  pl->o_tmp = take(std::max(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), pl->scan_chunks_tmp), pl->sort_tmp));
   pl->total_bytes = o;
   return SA_OK;
 }
@@ -1263,10 +1536,12 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   uint32_t* chunk_base = (uint32_t*)(ws + pl.o_chunk_base);
   uint32_t* windows = (uint32_t*)(ws + pl.o_windows);
   uint32_t* wbase = (uint32_t*)(ws + pl.o_wbase);
-  uint32_t* counter = (uint32_t*)(ws + pl.o_counter);
-  uint32_t* n_unresolved = counter + b->n;
-  uint32_t* n_big = counter + b->n + 1;
-  uint32_t* other = counter + b->n + 2;
+  uint32_t* flags = (uint32_t*)(ws + pl.o_flags);
+  uint32_t* n_unresolved = flags;
+  uint32_t* n_big = flags + 1;
+  uint32_t* other = flags + 2;
+  uint32_t* chunk_count = (uint32_t*)(ws + pl.o_chunk_count);
+  uint32_t* cscan = (uint32_t*)(ws + pl.o_cscan);
   uint64_t* keys = (uint64_t*)(ws + pl.o_keys);
   uint64_t* sorted = (uint64_t*)(ws + pl.o_sorted);
   uint32_t* seg_begin = (uint32_t*)(ws + pl.o_seg_begin);
@@ -1288,7 +1563,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.chunk = pl.chunk;
   a.chunk_base = chunk_base;
   a.wbase = wbase;
-  a.counter = counter;
+  a.chunk_count = chunk_count;
   a.exit_f = (uint32_t*)(ws + pl.o_exit_f);
   a.exit_c = (uint32_t*)(ws + pl.o_exit_c);
   a.resolved = (uint8_t*)(ws + pl.o_resolved);
@@ -1302,11 +1577,13 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   if (pl.buckets) {  // one sequence: the bookkeeping in one launch, the bucket tables cleared alongside
     SA_HIP_TRY(hipMemsetAsync(ws + pl.o_bucket_zero, 0, pl.bucket_zero_bytes, stream));
     hipLaunchKernelGGL(min_plan_single, dim3(1), dim3(64), 0, stream, b->d_off, b->k, b->w, pl.chunk, nchunks,
-                       chunk_base, windows, wbase, counter, b->d_status);
+                       chunk_base, windows, wbase, flags, b->d_status);
   } else {
     if (b->d_status) SA_HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), stream));
-    SA_HIP_TRY(hipMemsetAsync(counter, 0, ((size_t)b->n + 3) * 4, stream));
+    SA_HIP_TRY(hipMemsetAsync(flags, 0, 16, stream));
     SA_HIP_TRY(hipMemsetAsync(tile_count, 0, ((size_t)pl.max_tiles + 1) * 4, stream));
+    if (!pl.direct)  // (the scan over the chunks' counts runs over the whole array)
+      SA_HIP_TRY(hipMemsetAsync(chunk_count, 0, ((size_t)pl.max_chunks + 1) * 4, stream));
     hipLaunchKernelGGL(min_seq_plan, blocks(b->n + 1), dim3(kThreads), 0, stream, b->d_off, b->n, b->k,
                        b->w, pl.chunk, nchunks, windows);
     t = pl.scan32_tmp;
@@ -1318,18 +1595,18 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   }
   if (b->variant == SA_MIN_BINARY) {
     const bool long_k = b->k > 16;  // a third history word
-    auto* run = long_k     ? min_run<Machine<0, true>>
-                : b->w == 5  ? min_run<Machine<5>>
-                : b->w == 10 ? min_run<Machine<10>>
-                             : min_run<Machine<0>>;
+    auto* run = long_k                    ? min_run<Machine<0, true>, 0>
+                : (b->w == 5 && b->k == 15) ? min_run<Machine<5>, 15>
+                : b->w == 5                 ? min_run<Machine<5>, 0>
+                : b->w == 10                ? min_run<Machine<10>, 0>
+                                            : min_run<Machine<0>, 0>;
     hipLaunchKernelGGL(run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
     auto* fix = long_k ? min_fix<Machine<0, true>> : min_fix<Machine<0>>;
     hipLaunchKernelGGL(fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
     // a batch with bytes other than bases runs again on the exact machine (the three kernels return at
     // once otherwise)
-    hipLaunchKernelGGL(min_redo_reset, blocks((uint64_t)b->n + 1), dim3(kThreads), 0, stream, counter, b->n,
-                       other, a.hist, kFine);
-    auto* run_x = long_k ? min_run<MachineX<true>> : min_run<MachineX<false>>;
+    hipLaunchKernelGGL(min_redo_reset, dim3(64), dim3(kThreads), 0, stream, n_unresolved, other, a.hist, kFine);
+    auto* run_x = long_k ? min_run<MachineX<true>, 0> : min_run<MachineX<false>, 0>;
     auto* fix_x = long_k ? min_fix<MachineX<true>> : min_fix<MachineX<false>>;
     hipLaunchKernelGGL(run_x, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
     hipLaunchKernelGGL(fix_x, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
@@ -1341,7 +1618,10 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     BucketArgs ba{};
     ba.keys = keys;
     ba.grouped = sorted;
-    ba.count = counter;
+    ba.nchunks = nchunks;
+    ba.chunk_count = chunk_count;
+    ba.chunk = pl.chunk;
+    ba.key_shift = pl.key_shift;
     ba.fine_shift = pl.fine_shift;
     ba.hist = (uint32_t*)(ws + pl.o_hist);
     ba.nseg = pl.nseg;
@@ -1352,8 +1632,8 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ba.seg_lokey = (uint64_t*)(ws + pl.o_bseg_lokey);
     ba.seg_span = (uint64_t*)(ws + pl.o_bseg_span);
     ba.nseg_used = (uint32_t*)((uint64_t*)(ws + pl.o_bscan) + pl.nseg + 1);
-    // (one key per thread where the grid allows: the scatter is a chain of atomics that return a value)
-    const dim3 sweep((unsigned)std::min<uint64_t>(pl.capacity / (2 * kThreads) + 1, 65535));
+    // (a wave per chunk; the scatter is a chain of atomics that return a value)
+    const dim3 sweep((unsigned)std::min<uint64_t>(pl.max_chunks / (kThreads / 64) + 1, 65535));
     hipLaunchKernelGGL(bucket_plan, dim3(1), dim3(kThreads), 0, stream, ba);
     hipLaunchKernelGGL(bucket_scatter, sweep, dim3(kThreads), 0, stream, ba);
     hipLaunchKernelGGL(bucket_split, dim3(pl.nseg), dim3(kThreads), 0, stream, ba);
@@ -1382,24 +1662,50 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     SA_HIP_TRY(hipGetLastError());
     return SA_OK;
   }
-  hipLaunchKernelGGL(min_segments, blocks(b->n + 1), dim3(kThreads), 0, stream, wbase, counter, b->n,
-                     seg_begin, seg_end, big_end, tiles, n_big);
-  SA_HIP_TRY(hipGetLastError());
-  t = pl.scan32_tmp;
-  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tiles, tile_base, 0u, (size_t)b->n + 1,
+  if (pl.direct) {
+    // reads: no sequence with more than kSmallMax keys, as a rule - one kernel collects a read's chunks, sorts,
+    // removes duplicates and writes the triples; otherwise it returns at once and the kernels after it do the work
+    hipLaunchKernelGGL(min_count_direct, blocks(b->n), dim3(kThreads), 0, stream, a, seg_begin, n_big);
+    EmitArgs ea{};
+    ea.keys = keys;
+    ea.seg_begin = seg_begin;  // (direct: the sequences' key counts)
+    ea.seg_end = seg_end;
+    ea.n = b->n;
+    ea.key_shift = pl.key_shift;
+    ea.value_bits = pl.end_bit - pl.key_shift;
+    ea.scan_state = (uint64_t*)(ws + pl.o_scan_state);
+    ea.ticket = (uint32_t*)(ea.scan_state + b->n);
+    ea.n_big = n_big;
+    ea.out_capacity = b->out_capacity;
+    ea.out = b->d_out;
+    ea.out_off = b->d_out_off;
+    ea.status = b->d_status;
+    ea.direct = 1;
+    ea.chunk_base = chunk_base;
+    ea.chunk_count = chunk_count;
+    ea.wbase = wbase;
+    ea.chunk = pl.chunk;
+    SA_HIP_TRY(hipMemsetAsync(ea.scan_state, 0, ((size_t)b->n + 1) * 8, stream));
+    hipLaunchKernelGGL(sort_emit_small, dim3(b->n), dim3(kThreads), 0, stream, ea);
+    SA_HIP_TRY(hipGetLastError());
+    // sequences of at most kSmallMax windows cannot have more keys: nothing is left to do
+    if ((uint64_t)b->max_len - (b->k + b->w - 2) <= kSmallMax) return SA_OK;
+  }
+  // The several-kernel path: the chunks' keys are packed into `sorted`, sequence by sequence, and sorted from
+  // there back into `keys`.  (After sort_emit_small has served a batch of reads every kernel below returns at
+  // once or finds only empty segments.)
+  t = pl.scan_chunks_tmp;
+  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, chunk_count, cscan, 0u, (size_t)pl.max_chunks + 1,
                                      rocprim::plus<uint32_t>(), stream));
-  t = pl.sort_tmp;
-  const bool all_small = b->n > 1 && (uint64_t)b->max_len - (b->k + b->w - 2) <= kSmallMax;
-  if (b->n == 1) {
-    // one long sequence: a device-wide sort of exactly its keys (their number is needed on the host)
-    uint32_t count = 0;
-    SA_HIP_TRY(hipMemcpyAsync(&count, counter, 4, hipMemcpyDeviceToHost, stream));
-    SA_HIP_TRY(hipStreamSynchronize(stream));
-    if (count)
-      SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
-  } else {
-    // no sequence with more than kSmallMax keys (reads): one kernel sorts, removes duplicates and writes
-    // the triples; otherwise it returns at once and the kernels after it do the work
+  hipLaunchKernelGGL(compact_keys, dim3(std::min<uint32_t>(pl.max_chunks, 16384)), dim3(kThreads), 0, stream, a,
+                     cscan, sorted, pl.direct ? n_big : nullptr);
+  hipLaunchKernelGGL(min_segments, blocks(b->n + 1), dim3(kThreads), 0, stream, cscan, chunk_base, b->n,
+                     seg_begin, seg_end, big_end, tiles, n_big, pl.direct ? 0u : 1u);
+  SA_HIP_TRY(hipGetLastError());
+  std::swap(keys, sorted);  // keys: packed, unsorted; sorted: the sort's output
+  if (!pl.direct && b->n > 1) {
+    // sequences of many chunks each, none with more than kSmallMax keys: sort_emit_small on the packed keys
+    // (it returns at once otherwise)
     EmitArgs ea{};
     ea.keys = keys;
     ea.seg_begin = seg_begin;
@@ -1416,12 +1722,24 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.status = b->d_status;
     SA_HIP_TRY(hipMemsetAsync(ea.scan_state, 0, ((size_t)b->n + 1) * 8, stream));
     hipLaunchKernelGGL(sort_emit_small, dim3(b->n), dim3(kThreads), 0, stream, ea);
+  }
+  t = pl.scan32_tmp;
+  SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tiles, tile_base, 0u, (size_t)b->n + 1,
+                                     rocprim::plus<uint32_t>(), stream));
+  t = pl.sort_tmp;
+  if (b->n == 1) {
+    // one long sequence: a device-wide sort of exactly its keys (their number is needed on the host)
+    uint32_t count = 0;
+    SA_HIP_TRY(hipMemcpyAsync(&count, seg_end, 4, hipMemcpyDeviceToHost, stream));
+    SA_HIP_TRY(hipStreamSynchronize(stream));
+    if (count)
+      SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
+  } else {
     hipLaunchKernelGGL(sort_small, dim3(b->n), dim3(kThreads), 0, stream, keys, sorted, seg_begin, seg_end,
                        tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift, n_big);
     SA_HIP_TRY(hipGetLastError());
-    if (!all_small)
-      SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
-                                                    seg_begin, big_end, 0u, pl.end_bit, stream));
+    SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
+                                                  seg_begin, big_end, 0u, pl.end_bit, stream));
   }
   UniqArgs u{};
   u.sorted = sorted;
@@ -1439,7 +1757,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   u.out_off = b->d_out_off;
   u.status = b->d_status;
   const dim3 grid(std::min<uint32_t>(pl.max_tiles, 16384));
-  if (!all_small) hipLaunchKernelGGL(uniq_count, grid, dim3(kThreads), 0, stream, u);
+  hipLaunchKernelGGL(uniq_count, grid, dim3(kThreads), 0, stream, u);
   SA_HIP_TRY(hipGetLastError());
   t = pl.scan64_tmp;
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tile_count, tile_off, (uint64_t)0,

@@ -40,7 +40,6 @@
 namespace sa {
 
 constexpr uint32_t kWarm = 160;   // warm-up steps in front of a chunk
-constexpr int kBuf = 16;          // keys a lane can hold in LDS before the wave flushes
 constexpr uint32_t kTile = 2048;  // sorted keys per block in the unique pass
 
 struct MinArgs {
@@ -52,11 +51,11 @@ struct MinArgs {
   uint32_t chunk;              // windows per chunk (multiple of 8)
   const uint32_t* chunk_base;  // n + 1: first chunk of every sequence
   const uint32_t* wbase;       // n + 1: first key slot of every sequence (exclusive scan of its windows)
-  uint32_t* counter;           // n: keys written so far per sequence
+  uint32_t* chunk_count;       // per chunk: keys it wrote, from key slot wbase[sequence] + its first window on
   uint32_t* exit_f;            // per chunk: forward-strand state after the chunk's last window
   uint32_t* exit_c;            // per chunk: other-strand state
   uint8_t* resolved;           // per chunk: 1 once its keys are written and its exit state is final
-  uint64_t* keys;              // candidate keys; sequence s owns [wbase[s], wbase[s] + counter[s])
+  uint64_t* keys;              // candidate keys, one slot per window
   int* status;
   uint32_t* other;             // set to 1 by a thread that met a byte other than ACGT / acgt
   // single-sequence calls: every key written is also counted in the histogram of the bucketed sort

@@ -2,7 +2,9 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from sequencealigner_amd import minimize, synth
+from sequencealigner_amd import capi, minimize, synth
+if os.environ.get("SA_LIB"):   # a library built with other options (kernel experiments)
+    capi.LIB_PATH = os.path.abspath(os.environ["SA_LIB"])
 torch.cuda.set_device(0)
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 shapes = []
