@@ -63,11 +63,12 @@ __global__ void min_plan_single(const uint64_t* off, uint32_t k, uint32_t w, uin
 // scan; the consumers (sort_emit_small for reads, bucket_scatter for one long sequence, compact_keys for the
 // rest) walk a sequence's chunks.  What is stored is the RAW key: value in the low word, position << 1 |
 // strand in the high word (compose_key shifts them together); lanes collect raw keys in LDS (kBuf slots each)
-// and the wave writes them out together, 16 lanes per source lane and 16 bytes per lane, so that a store
-// instruction covers four lanes' runs of up to 256 contiguous bytes instead of 64 scattered keys.
-constexpr int kBuf = 24;
-constexpr uint32_t kFlushAt = kBuf - 9;  // a check every 8 steps: flush when some lane holds more keys than this
-static_assert(kBuf <= 32 && kBuf % 2 == 0, "one pass of flush_keys covers 32 keys per lane");
+// and the wave writes them out together, kCopyLanes lanes per source lane and 16 bytes per lane, so that a
+// store instruction covers eight lanes' runs of up to 128 contiguous bytes instead of 64 scattered keys.
+constexpr int kBuf = 16;                 // (36 KB of LDS per block with the flush headers: four blocks per CU)
+constexpr uint32_t kFlushAt = kBuf - 5;  // a check every 4 steps: flush when some lane holds more keys than this
+constexpr uint32_t kCopyLanes = kBuf / 2;  // lanes that copy one source lane's keys, two keys each
+static_assert(kBuf % 2 == 0 && 64 % kCopyLanes == 0, "flush_keys: whole teams of kCopyLanes lanes per wave");
 
 __device__ __forceinline__ uint64_t compose_key(uint64_t raw, uint32_t key_shift) {
   return ((uint64_t)(uint32_t)raw << key_shift) | (raw >> 32);
@@ -90,7 +91,8 @@ struct FlushHeader {  // what a lane tells the lanes that copy its keys
 template <uint32_t SHIFT>
 __device__ __forceinline__ void flush_keys(const MinArgs& a, uint2 (*buf)[kThreads], FlushHeader* hdr, uint32_t tid,
                                            KeyOut& o) {
-  const uint32_t lane = tid & 63, team = lane >> 4, idx = lane & 15;
+  constexpr uint32_t kTeams = 64 / kCopyLanes;
+  const uint32_t lane = tid & 63, team = lane / kCopyLanes, idx = lane % kCopyLanes;
   FlushHeader mine;
   mine.to = o.dst + o.written;
   mine.cnt = o.ok ? o.cnt : 0;
@@ -99,14 +101,10 @@ __device__ __forceinline__ void flush_keys(const MinArgs& a, uint2 (*buf)[kThrea
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS accesses of one wave execute in program order)
   __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-  for (uint32_t g = 0; g < 16; ++g) {
-    const uint32_t src = (tid - lane) + g * 4 + team;
+  for (uint32_t g = 0; g < 64 / kTeams; ++g) {
+    const uint32_t src = (tid - lane) + g * kTeams + team;
     const FlushHeader h = hdr[src];
-    uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
-    if (2 * idx < (uint32_t)kBuf) {
-      e0 = buf[2 * idx][src];
-      e1 = buf[2 * idx + 1][src];
-    }
+    uint2 e0 = buf[2 * idx][src], e1 = buf[2 * idx + 1][src];
     e0.x >>= SHIFT;
     e1.x >>= SHIFT;
     if (2 * idx + 1 < h.cnt) {
@@ -142,6 +140,37 @@ __device__ __forceinline__ uint4 load16_guard(const uint8_t* p, const uint8_t* e
   }
   return make_uint4(w3, w2, w1, w0);  // byte 0 ended in the low byte of w3
 }
+
+// A lane's bases in order, 16 bytes per load with the next 16 already on their way: the steps in front of a
+// chunk (history, candidate sets) would otherwise wait for a byte load each.
+struct ByteStream {
+  const uint8_t* p;    // address of the next byte
+  const uint8_t* end;
+  uint4 cur, nxt;      // cur: the bytes from p on, shifted down as they are taken; nxt: the 16 bytes after cur's
+  uint32_t left;       // bytes left in cur
+  __device__ __forceinline__ void open(const uint8_t* from, const uint8_t* end_) {
+    p = from;
+    end = end_;
+    cur = load16_guard(p, end);
+    nxt = load16_guard(p + 16, end);
+    left = 16;
+  }
+  __device__ __forceinline__ uint32_t next() {
+    if (left == 0) {
+      cur = nxt;
+      nxt = load16_guard(p + 16, end);
+      left = 16;
+    }
+    const uint32_t byte = cur.x & 0xFFu;
+    cur.x = __builtin_amdgcn_alignbit(cur.y, cur.x, 8);
+    cur.y = __builtin_amdgcn_alignbit(cur.z, cur.y, 8);
+    cur.z = __builtin_amdgcn_alignbit(cur.w, cur.z, 8);
+    cur.w >>= 8;
+    ++p;
+    --left;
+    return byte;
+  }
+};
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
@@ -202,7 +231,7 @@ __device__ __forceinline__ void fast_block16(FM& fm, uint32_t r0, const uint4& b
       ex_pf = last ? fm.pf + r0 : ex_pf;
       ex_pc = last ? fm.pc + r0 : ex_pc;
     }
-    if (MODE != 0 && (U & 7) == 7) {
+    if (MODE != 0 && (U & 3) == 3) {
       o.cnt = (slot - tid * 8u) / kSlotBytes;
       if (__any(o.cnt > kFlushAt)) {
         flush_keys<S>(a, buf, hdr, tid, o);
@@ -260,19 +289,35 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   };
   bool live = valid, sets = false;
   uint32_t Mf = 1, Mc = 1;
+  // The bases in front of the chunk: close to the sequence start (the warm-up would begin before k-mer k + 1,
+  // whose candidates reach back to position 0) the windows before the chunk run exactly, from window 0;
+  // elsewhere the chunk starts kWarm windows early with every candidate state of step j, the positions
+  // j-k-1 .. j-1.
+  const bool from_start = valid && F <= kWarm + k + 2;
+  uint32_t first_base = 0, n_push = 0;  // the history: bases first_base .. first_base + n_push - 1
   if (valid) {
-    // close to the sequence start (the warm-up would begin before k-mer k + 1, whose candidates reach back
-    // to position 0): run the windows before the chunk exactly
-    if (F <= kWarm + k + 2) {
-      for (uint32_t b = 0; b < w + k - 1; ++b) m.push(M::feed1(s[b], other));
+    if (from_start) {
+      n_push = w + k - 1;
+    } else {
+      i = F - kWarm;
+      first_base = (i + w - 1) - k - 1;
+      n_push = 2 * k;
+    }
+  }
+  ByteStream in;
+  in.open(s + first_base, blob_end);
+  {
+    const uint32_t max_push = wave_max_u32(n_push);
+    for (uint32_t b = 0; b < max_push; ++b)
+      if (b < n_push) m.push(M::feed1(in.next(), other));
+  }
+  if (valid) {
+    if (from_start) {
       m.first_window();
       if (F == 0) emit();
       i = 1;
-    } else {  // candidates of step j are the positions j-k-1 .. j-1
-      i = F - kWarm;
-      const uint32_t j = i + w - 1;
-      for (uint32_t b = j - k - 1; b + 1 < j + k; ++b) m.push(M::feed1(s[b], other));
-      m.j = j;
+    } else {
+      m.j = i + w - 1;
       m.init_window();
       Mf = Mc = (2u << k) - 1u;
       sets = true;
@@ -281,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   for (uint32_t guard = 0; guard < kWarm; ++guard) {
     if (!__any(sets && (__builtin_popcount(Mf) != 1 || __builtin_popcount(Mc) != 1))) break;
     if (sets) {
-      m.step_sets(M::feed1(s[m.j + k - 1], other), Mf, Mc);
+      m.step_sets(M::feed1(in.next(), other), Mf, Mc);
       ++i;
     }
   }
@@ -697,20 +742,25 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds, uint32_
 constexpr uint32_t kSmallMax = kTile;
 constexpr uint32_t kBins = 2048;
 
-// Minimizer values crowd the low end of their range with a long tail, so the bins are spaced like a
-// small floating-point format: 16 octaves below 2^value_bits with 128 bins each; smaller values share bin 0.
-__device__ __forceinline__ uint32_t value_bin(uint32_t v, uint32_t value_bits) {
+// Minimizer values crowd the low end of their range: a window's value is the smallest of about 2 w k-mer values
+// (both strands), so its distribution function is about 1 - (1 - x)^(2w) for x = value / 2^value_bits.  The bins
+// follow that function (in 32-bit fixed point, powers by repeated squaring), which spreads the keys of a random
+// sequence evenly over them; any non-decreasing function sorts correctly, an uneven one only costs time.
+__device__ __forceinline__ uint32_t value_bin(uint32_t v, uint32_t value_bits, uint32_t power) {
   if (value_bits <= 11) return v;
-  const uint32_t lz = __builtin_clz(v | 1u);
-  const int octave = (int)(31 - lz) - (value_bits > 16 ? (int)value_bits - 16 : 0);
-  const uint32_t mant = (lz == 31) ? 0u : ((v << (lz + 1)) >> 25);
-  return octave < 0 ? 0u : (uint32_t)octave * 128u + mant;
+  uint32_t t = ~(v << (32 - value_bits));  // 1 - x
+  uint32_t acc = 0xFFFFFFFFu;              // (1 - x)^0
+  for (uint32_t m = power; m; m >>= 1) {   // (the same trip count in every lane)
+    if (m & 1u) acc = __umulhi(acc, t);
+    t = __umulhi(t, t);
+  }
+  return (~acc) >> 21;                     // 2048 bins
 }
 
 __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uint64_t* sorted,
                                                        const uint32_t* seg_begin, const uint32_t* seg_end,
                                                        const uint32_t* tile_base, uint32_t* tile_count,
-                                                       uint32_t key_shift, uint32_t value_bits,
+                                                       uint32_t key_shift, uint32_t value_bits, uint32_t power,
                                                        const uint32_t* n_big) {
   __shared__ uint64_t grouped[kSmallMax];
   __shared__ uint32_t bins[kBins];
@@ -730,7 +780,7 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
     const uint32_t i = tid + e * kThreads;
     if (i < count) {
       mine[e] = keys[begin + i];
-      bin[e] = value_bin((uint32_t)(mine[e] >> key_shift), value_bits);
+      bin[e] = value_bin((uint32_t)(mine[e] >> key_shift), value_bits, power);
       atomicAdd(&bins[bin[e]], 1u);
     }
   }
@@ -760,7 +810,7 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
   uint32_t uniq = 0;
   for (uint32_t p = tid; p < count; p += kThreads) {
     const uint64_t key = grouped[p];
-    const uint32_t b = value_bin((uint32_t)(key >> key_shift), value_bits);
+    const uint32_t b = value_bin((uint32_t)(key >> key_shift), value_bits, power);
     const uint32_t lo = b ? bins[b - 1] : 0, hi = bins[b];
     uint32_t rank = 0;
     bool dup = false;
@@ -795,6 +845,7 @@ struct EmitArgs {
   const uint32_t* seg_end;
   uint32_t n;
   uint32_t key_shift, value_bits;
+  uint32_t power;        // exponent of value_bin's distribution function
   uint64_t* scan_state;  // n entries, zeroed: flag << 62 | value
   uint32_t* ticket;      // zeroed
   const uint32_t* n_big; // sequences with more than kSmallMax keys
@@ -821,19 +872,23 @@ struct EmitArgs {
   const uint32_t* wbase;
   uint32_t chunk;
 };
-constexpr uint32_t kDirectChunks = 32;
+constexpr uint32_t kDirectChunks = 8;
 
+enum { kEmitPacked = 0, kEmitDirect = 1, kEmitBuckets = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   // one buffer, two uses: [0, 4096) grouped keys + [4096, 5120) bin counters (16 bits each, two per dword)
-  // while sorting, then the staged (value, position << 1 | strand) pairs.  20.3 KB with the small arrays below
-  // and 65 registers: seven blocks per CU (a leaner form that fits eight ran no faster).
+  // while sorting, then the staged (value, position << 1 | strand) pairs.  20.3 KB with the small arrays below:
+  // seven blocks per CU.
   __shared__ __attribute__((aligned(16))) uint32_t buf[2 * kSmallMax + kBins / 2];
   __shared__ uint32_t lds[kThreads / 64];
-  __shared__ uint32_t dup_rank[64];  // ranks of keys that repeat their predecessor (few, if any)
-  __shared__ uint32_t s_seq, s_ndup;
+  __shared__ uint32_t distinct[kSmallMax / 32];  // bit r: the key of sorted rank r is the first of its value
+  __shared__ uint32_t s_seq;
   __shared__ uint64_t s_excl;
   __shared__ uint64_t lb_sum[kThreads / 64];   // look-back: per wave, the counts it may add
   __shared__ uint32_t lb_flag[kThreads / 64];  //   bit 0: usable, bit 1: ends at a prefix
+  __shared__ uint32_t ccount[kDirectChunks];   // direct: the key counts of the sequence's chunks
   uint64_t* grouped = reinterpret_cast<uint64_t*>(buf);
   uint32_t* bins2 = buf + 2 * kSmallMax;  // bin b: half b & 1 of bins2[b >> 1] (counts and positions <= 2048)
   uint32_t* stage = buf;
@@ -843,285 +898,311 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
     return (atomicAdd(&bins2[b >> 1], 1u << (16 * (b & 1))) >> (16 * (b & 1))) & 0xFFFFu;
   };
   const uint32_t tid = threadIdx.x;
-  if (!a.buckets && *a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
-  if (tid == 0) {
-    s_seq = atomicAdd(a.ticket, 1u);
-    s_ndup = 0;
-  }
-  __syncthreads();
-  const uint32_t s = s_seq;
-  const uint32_t nsegs = a.buckets ? *a.nseg_used : a.n;
-  if (s >= nsegs) return;
-  __shared__ uint32_t cpre[kDirectChunks + 1];  // direct: exclusive prefix of the sequence's chunk counts
-  const uint32_t begin = a.direct ? a.wbase[s] : a.seg_begin[s];
-  uint32_t count = a.direct ? a.seg_begin[s] : a.seg_end[s] - begin;  // <= kSmallMax: n_big == 0, bucket_split
-  uint32_t nch = 0;
-  if (a.direct) {
-    const uint32_t c0 = a.chunk_base[s];
-    nch = a.chunk_base[s + 1] - c0;  // <= kDirectChunks (the host checks the bound)
-    if (tid == 0) {
-      uint32_t sum = 0;
-      for (uint32_t x = 0; x < nch; ++x) {
-        cpre[x] = sum;
-        sum += a.chunk_count[c0 + x];
-      }
-      cpre[nch] = sum;
-    }
-    __syncthreads();
-  }
-  uint32_t ch = 0;  // direct: the chunk of the key loaded last (a thread's keys come in increasing order)
-  auto load_key = [&](uint32_t i) -> uint64_t {  // key i of the sequence
-    if (!a.direct) return a.keys[begin + i];
-    while (ch + 1 < nch && cpre[ch + 1] <= i) ++ch;
-    return compose_key(a.keys[(uint64_t)begin + (uint64_t)ch * a.chunk + (i - cpre[ch])], a.key_shift);
-  };
-  if (count > kSmallMax) {                // never expected: fail the call rather than overrun the buffers
-    if (tid == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
-    count = kSmallMax;
-  }
-  constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
-  // the bin of a key: reads - a function of the value; buckets - linear between the bucket's bounds
-  uint64_t lokey = 0;
-  uint32_t bshift = 0;
-  if (a.buckets && count) {
-    uint64_t span;
-    if (a.seg_hif[s]) {
-      lokey = (uint64_t)a.seg_lof[s] << a.fine_shift;
-      span = (uint64_t)(a.seg_hif[s] - a.seg_lof[s]) << a.fine_shift;
+  if (MODE != kEmitBuckets && *a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
+  const uint32_t nsegs = MODE == kEmitBuckets ? *a.nseg_used : a.n;
+  // Which segment a block takes.  A block waits, in the look-back, for the segments before its own, so those must
+  // belong to blocks that run or have finished.  Buckets (a few hundred blocks): numbers from a ticket counter, in
+  // start order.  Reads: the block's own number - a returning atomic per block on ONE word would bound the
+  // kernel at about 90 blocks per microsecond (it did: 1.1 of 1.8 ms for 10^5 reads).  Every XCD starts its
+  // share of the blocks in increasing order, so the lowest-numbered unfinished segment always finds a free slot
+  // on its XCD (everything before it on that XCD has finished) and needs no other block: the launch cannot stall;
+  // the look-back's waits are bounded all the same and fail the call rather than hang.
+  for (uint32_t round = 0; round < 1; ++round) {
+    uint32_t s;
+    if (MODE == kEmitBuckets) {
+      if (tid == 0) s_seq = atomicAdd(a.ticket, 1u);
+      __syncthreads();
+      s = s_seq;
     } else {
-      lokey = a.seg_lokey[s];
-      span = a.seg_span[s];
+      s = blockIdx.x;
     }
-    const uint32_t bits = span > 1 ? 64u - (uint32_t)__builtin_clzll(span - 1) : 0u;
-    bshift = bits > 11 ? bits - 11 : 0;
-  }
-  auto bin_of = [&](uint64_t key) -> uint32_t {
-    if (!a.buckets) return value_bin((uint32_t)(key >> a.key_shift), a.value_bits);
-    const uint64_t b = (key - lokey) >> bshift;
-    return b < kBins ? (uint32_t)b : kBins - 1;
-  };
-#pragma unroll
-  for (uint32_t e = 0; e < kBinsPer / 2; ++e) bins2[tid + e * kThreads] = 0;
-  __syncthreads();
-  uint64_t mine[kPer];
-  uint32_t bin[kPer];
-#pragma unroll
-  for (uint32_t e = 0; e < kPer; ++e) {
-    const uint32_t i = tid + e * kThreads;
-    if (i < count) {
-      mine[e] = load_key(i);
-      bin[e] = bin_of(mine[e]);
-      bin_inc(bin[e]);
-    }
-  }
-  __syncthreads();
-  // exclusive scan of the bin counts: thread t owns bins t * kBinsPer .. (kBinsPer / 2 dwords)
-  uint32_t local[kBinsPer], sum = 0;
-#pragma unroll
-  for (uint32_t e = 0; e < kBinsPer / 2; ++e) {
-    const uint32_t w = bins2[tid * (kBinsPer / 2) + e];
-    local[2 * e] = w & 0xFFFFu;
-    local[2 * e + 1] = w >> 16;
-    sum += local[2 * e] + local[2 * e + 1];
-  }
-  uint32_t excl;
-  block_sum(sum, lds, &excl);
-#pragma unroll
-  for (uint32_t e = 0; e < kBinsPer / 2; ++e) {
-    const uint32_t lo16 = excl, hi16 = excl + local[2 * e];
-    bins2[tid * (kBinsPer / 2) + e] = lo16 | (hi16 << 16);
-    excl = hi16 + local[2 * e + 1];
-  }
-  __syncthreads();
-#pragma unroll
-  for (uint32_t e = 0; e < kPer; ++e) {
-    const uint32_t i = tid + e * kThreads;
-    if (i < count) grouped[bin_inc(bin[e])] = mine[e];
-  }
-  __syncthreads();
-  // bins[b] is now the end of bin b: rank every key among the keys of its bin; a key that has an equal key
-  // before it is a duplicate and is dropped
-  uint32_t rank[kPer];
-#pragma unroll
-  for (uint32_t e = 0; e < kPer; ++e) {
-    const uint32_t p = tid + e * kThreads;
-    rank[e] = ~0u;
-    if (p < count) {
-      const uint64_t key = grouped[p];
-      mine[e] = key;
-      const uint32_t b = bin_of(key);
-      const uint32_t lo = b ? bin_get(b - 1) : 0, hi = bin_get(b);
-      uint32_t r = lo;
-      bool dup = false;
-      for (uint32_t m = lo; m < hi; ++m) {
-        const uint64_t other = grouped[m];
-        const bool same_before = other == key && m < p;
-        r += (other < key || same_before) ? 1u : 0u;
-        dup |= same_before;
+    if (s >= nsegs) return;
+    {
+      if (tid < kSmallMax / 32) distinct[tid] = 0;
+      __syncthreads();
+      const uint32_t begin = MODE == kEmitDirect ? a.wbase[s] : a.seg_begin[s];
+      uint32_t count = MODE == kEmitDirect ? a.seg_begin[s] : a.seg_end[s] - begin;  // <= kSmallMax: n_big == 0, bucket_split
+      if (count > kSmallMax) {  // never expected: fail the call rather than overrun the buffers
+        if (tid == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
+        count = kSmallMax;
       }
-      if (dup) {
-        const uint32_t at = atomicAdd(&s_ndup, 1u);
-        if (at < 64) dup_rank[at] = r;
-        r |= 0x80000000u;
-      }
-      rank[e] = r;
-    }
-  }
-  __syncthreads();  // grouped / bins are free from here on
-  const uint32_t ndup = s_ndup;
-  const uint32_t uniq = count - ndup;
-  // this sequence's place among all sequences: look back over the predecessors' counts.  Reads: one wave,
-  // 64 predecessors at a time (blocks finish at different times, most find a prefix within a window or two).
-  if (!a.buckets && tid < 64) {
-    const uint32_t lane = tid;
-    if (lane == 0)
-      __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t before = 0;
-    int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
-    uint32_t polls = 0;
-    while (top >= 0) {
-      const int64_t idx = top - lane;
-      uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
-      if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t ready = __ballot((st >> 62) != 0);
-      const uint64_t final = __ballot((st >> 62) == 2);
-      // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the window
-      // has no prefix and all 64 are ready)
-      const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
-      const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
-      if ((ready & need) != need) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
-          if (lane == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
-          break;
+      constexpr uint32_t kPer = kSmallMax / kThreads, kBinsPer = kBins / kThreads;
+      // the bin of a key: reads - a function of the value; buckets - linear between the bucket's bounds
+      uint64_t lokey = 0;
+      uint32_t bshift = 0;
+      if (MODE == kEmitBuckets && count) {
+        uint64_t span;
+        if (a.seg_hif[s]) {
+          lokey = (uint64_t)a.seg_lof[s] << a.fine_shift;
+          span = (uint64_t)(a.seg_hif[s] - a.seg_lof[s]) << a.fine_shift;
+        } else {
+          lokey = a.seg_lokey[s];
+          span = a.seg_span[s];
         }
-        continue;
+        const uint32_t bits = span > 1 ? 64u - (uint32_t)__builtin_clzll(span - 1) : 0u;
+        bshift = bits > 11 ? bits - 11 : 0;
       }
-      uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      before += v;
-      if (final) break;
-      top -= 64;
-    }
-    if (lane == 0) {
-      if (s != 0)
-        __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_excl = before;
-      a.out_off[s] = before;
-      if (s + 1 == a.n) {
-        a.out_off[a.n] = before + uniq;
-        if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
-      }
-    }
-  }
-  // Buckets of one sequence: all blocks run at once and finish together, nobody has a prefix yet: 256
-  // predecessors at a time (wave v
-  // takes the 64 predecessors from top - 64 v downwards); whole waves are used up in order until one meets a
-  // predecessor that already carries its prefix, or one whose predecessors have not all published yet
-  if (a.buckets) {
-    const uint32_t lane = tid & 63, wv = tid >> 6;
-    if (tid == 0)
-      __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t before = 0;
-    int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
-    uint32_t polls = 0;
-    bool failed = false;
-    while (top >= 0) {
-      const int64_t idx = top - (int64_t)(wv * 64 + lane);
-      uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
-      if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t ready = __ballot((st >> 62) != 0);
-      const uint64_t final = __ballot((st >> 62) == 2);
-      // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the wave's
-      // window has no prefix and all 64 are ready)
-      const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
-      const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
-      uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) {
-        lb_sum[wv] = v;
-        lb_flag[wv] = ((ready & need) == need ? 1u : 0u) | (final ? 2u : 0u);
-      }
-      __syncthreads();
-      uint32_t used = 0;
-      bool done = false;
-      for (uint32_t x = 0; x < kThreads / 64 && !done; ++x) {
-        if (!(lb_flag[x] & 1u)) break;
-        before += lb_sum[x];
-        ++used;
-        done = (lb_flag[x] & 2u) != 0;
-      }
-      __syncthreads();
-      if (done) break;
-      top -= 64 * (int64_t)used;
-      if (used < kThreads / 64) {  // a wave's predecessors have not all published their counts yet
-        __builtin_amdgcn_s_sleep(1);
-        if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
-          failed = true;
-          break;
+      auto bin_of = [&](uint64_t key) -> uint32_t {
+        if (MODE != kEmitBuckets) return value_bin((uint32_t)(key >> a.key_shift), a.value_bits, a.power);
+        const uint64_t b = (key - lokey) >> bshift;
+        return b < kBins ? (uint32_t)b : kBins - 1;
+      };
+    #pragma unroll
+      for (uint32_t e = 0; e < kBinsPer / 2; ++e) bins2[tid + e * kThreads] = 0;
+      uint64_t mine[kPer];
+      if (MODE == kEmitDirect) {
+        // The sequence's keys lie where its chunks wrote them (raw).  Chunk by chunk they are copied into LDS, in
+        // order, and every thread takes its keys tid, tid + 256, ... from there: all loads of a chunk are in
+        // flight together and no thread has to look up which chunk holds its key.
+        const uint32_t c0 = a.chunk_base[s];
+        const uint32_t nch = a.chunk_base[s + 1] - c0;  // <= kDirectChunks (the host checks the bound)
+        if (tid < kDirectChunks) ccount[tid] = tid < nch ? a.chunk_count[c0 + tid] : 0u;
+        __syncthreads();
+        uint32_t at = 0;
+        for (uint32_t x = 0; x < nch; ++x) {
+          const uint32_t n = ccount[x];
+          const uint64_t* src = a.keys + (uint64_t)begin + (uint64_t)x * a.chunk;
+          for (uint32_t t = tid; t < n && at + t < kSmallMax; t += kThreads) grouped[at + t] = compose_key(src[t], a.key_shift);
+          at += n;
+        }
+        __syncthreads();
+    #pragma unroll
+        for (uint32_t e = 0; e < kPer; ++e) {
+          const uint32_t i = tid + e * kThreads;
+          mine[e] = i < count ? grouped[i] : 0;
+        }
+      } else {
+    #pragma unroll
+        for (uint32_t e = 0; e < kPer; ++e) {  // (all loads first)
+          const uint32_t i = tid + e * kThreads;
+          mine[e] = i < count ? a.keys[begin + i] : 0;
         }
       }
-    }
-    if (tid == 0) {
-      if (failed && a.status) atomicMax(a.status, SA_ERR_HIP);
-      if (s != 0)
-        __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_excl = before;
-      if (!a.buckets || s == 0) a.out_off[s] = before;
-      if (s + 1 == nsegs) {
-        a.out_off[a.buckets ? 1 : a.n] = before + uniq;
-        if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
+#ifdef SA_EXP_LOADONLY
+      if (mine[0] == 0x1234567 && mine[7] == 1) a.out[0] = 1;
+      continue;
+#endif
+      __syncthreads();  // the bin counters are cleared (and, direct, every thread has its keys out of LDS)
+      uint32_t bin[kPer];
+    #pragma unroll
+      for (uint32_t e = 0; e < kPer; ++e) {
+        const uint32_t i = tid + e * kThreads;
+        if (i < count) {
+          bin[e] = bin_of(mine[e]);
+          bin_inc(bin[e]);
+        }
+      }
+      __syncthreads();
+      // exclusive scan of the bin counts: thread t owns bins t * kBinsPer .. (kBinsPer / 2 dwords)
+      uint32_t local[kBinsPer], sum = 0;
+    #pragma unroll
+      for (uint32_t e = 0; e < kBinsPer / 2; ++e) {
+        const uint32_t w = bins2[tid * (kBinsPer / 2) + e];
+        local[2 * e] = w & 0xFFFFu;
+        local[2 * e + 1] = w >> 16;
+        sum += local[2 * e] + local[2 * e + 1];
+      }
+      uint32_t excl;
+      block_sum(sum, lds, &excl);
+    #pragma unroll
+      for (uint32_t e = 0; e < kBinsPer / 2; ++e) {
+        const uint32_t lo16 = excl, hi16 = excl + local[2 * e];
+        bins2[tid * (kBinsPer / 2) + e] = lo16 | (hi16 << 16);
+        excl = hi16 + local[2 * e + 1];
+      }
+      __syncthreads();
+      uint32_t place[kPer];  // where the key went in the grouped array
+    #pragma unroll
+      for (uint32_t e = 0; e < kPer; ++e) {
+        const uint32_t i = tid + e * kThreads;
+        if (i < count) {
+          place[e] = bin_inc(bin[e]);
+          grouped[place[e]] = mine[e];
+        }
+      }
+      __syncthreads();
+      // bins[b] is now the end of bin b: rank every key among the keys of its bin; a key that has an equal key
+      // before it in the grouped array is a duplicate and is dropped
+      uint32_t rank[kPer];
+    #pragma unroll
+      for (uint32_t e = 0; e < kPer; ++e) {
+        const uint32_t i = tid + e * kThreads;
+        rank[e] = ~0u;
+        if (i < count) {
+          const uint64_t key = mine[e];
+          const uint32_t b = bin[e], p = place[e];
+          const uint32_t lo = b ? bin_get(b - 1) : 0, hi = bin_get(b);
+          uint32_t r = lo;
+          bool dup = false;
+          for (uint32_t m = lo; m < hi; ++m) {
+            const uint64_t other = grouped[m];
+            const bool same_before = other == key && m < p;
+            r += (other < key || same_before) ? 1u : 0u;
+            dup |= same_before;
+          }
+          if (dup)
+            r |= 0x80000000u;
+          else
+            atomicOr(&distinct[r >> 5], 1u << (r & 31));
+          rank[e] = r;
+        }
+      }
+      __syncthreads();  // grouped / bins are free from here on
+      // Place of every distinct key among the distinct keys = distinct keys of smaller rank: every wave scans the
+      // 64 words of the bit map for itself (lane l holds word l and the number of bits in the words before it).
+      static_assert(kSmallMax / 32 == 64, "one word of the bit map per lane");
+      const uint32_t dword = distinct[tid & 63];
+      uint32_t dincl = __builtin_popcount(dword);
+    #pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(dincl, d);
+        if ((int)(tid & 63) >= d) dincl += t;
+      }
+      const uint32_t dexcl = dincl - __builtin_popcount(dword);
+      const uint32_t uniq = __shfl(dincl, 63);
+      uint32_t upos[kPer];
+    #pragma unroll
+      for (uint32_t e = 0; e < kPer; ++e) {
+        const uint32_t r = rank[e] & 0x7FFu;
+        const uint32_t before = __shfl(dexcl, r >> 5), word = __shfl(dword, r >> 5);
+        upos[e] = before + __builtin_popcount(word & ((1u << (r & 31)) - 1u));
+      }
+      // this sequence's place among all sequences: look back over the predecessors' counts.  Reads: one wave,
+      // 64 predecessors at a time (blocks finish at different times, most find a prefix within a window or two;
+      // all four waves on 256 predecessors, as below, took 13 % longer)
+#ifdef SA_EXP_NOLOOKBACK
+      if (tid == 0) { s_excl = (uint64_t)s * 1545; a.out_off[s] = s_excl; }
+      if (0) {
+#else
+      if (MODE != kEmitBuckets && tid < 64) {
+#endif
+        const uint32_t lane = tid;
+        if (lane == 0)
+          __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t before = 0;
+        int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
+        uint32_t polls = 0;
+        while (top >= 0) {
+          const int64_t idx = top - lane;
+          uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
+          if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t ready = __ballot((st >> 62) != 0);
+          const uint64_t final = __ballot((st >> 62) == 2);
+          // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the window
+          // has no prefix and all 64 are ready)
+          const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
+          const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
+          if ((ready & need) != need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
+              if (lane == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
+              break;
+            }
+            continue;
+          }
+          uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+          before += v;
+          if (final) break;
+          top -= 64;
+        }
+        if (lane == 0) {
+          if (s != 0)
+            __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_excl = before;
+          a.out_off[s] = before;
+          if (s + 1 == a.n) {
+            a.out_off[a.n] = before + uniq;
+            if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
+          }
+        }
+      }
+      // Buckets of one sequence: all blocks run at once and finish together, nobody has a prefix yet: 256
+      // predecessors at a time (wave v takes the 64 predecessors from top - 64 v downwards); whole waves are used
+      // up in order until one meets a predecessor that already carries its prefix, or one whose predecessors
+      // have not all published yet
+      if (MODE == kEmitBuckets) {
+        const uint32_t lane = tid & 63, wv = tid >> 6;
+        if (tid == 0)
+          __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t before = 0;
+        int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
+        uint32_t polls = 0;
+        bool failed = false;
+        while (top >= 0) {
+          const int64_t idx = top - (int64_t)(wv * 64 + lane);
+          uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
+          if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t ready = __ballot((st >> 62) != 0);
+          const uint64_t final = __ballot((st >> 62) == 2);
+          // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the wave's
+          // window has no prefix and all 64 are ready)
+          const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
+          const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
+          uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
+    #pragma unroll
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+          if (lane == 0) {
+            lb_sum[wv] = v;
+            lb_flag[wv] = ((ready & need) == need ? 1u : 0u) | (final ? 2u : 0u);
+          }
+          __syncthreads();
+          uint32_t used = 0;
+          bool done = false;
+          for (uint32_t x = 0; x < kThreads / 64 && !done; ++x) {
+            if (!(lb_flag[x] & 1u)) break;
+            before += lb_sum[x];
+            ++used;
+            done = (lb_flag[x] & 2u) != 0;
+          }
+          __syncthreads();
+          if (done) break;
+          top -= 64 * (int64_t)used;
+          if (used < kThreads / 64) {  // a wave's predecessors have not all published their counts yet
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
+              failed = true;
+              break;
+            }
+          }
+        }
+        if (tid == 0) {
+          if (failed && a.status) atomicMax(a.status, SA_ERR_HIP);
+          if (s != 0)
+            __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_excl = before;
+          if (s == 0) a.out_off[s] = before;
+          if (s + 1 == nsegs) {
+            a.out_off[1] = before + uniq;
+            if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
+          }
+        }
+      }
+      const uint64_t low = (1ull << a.key_shift) - 1;
+    #pragma unroll
+      for (uint32_t e = 0; e < kPer; ++e) {
+        if (rank[e] & 0x80000000u) continue;  // beyond the keys, or a duplicate
+        const uint32_t u = upos[e];
+        stage[2 * u] = (uint32_t)(mine[e] >> a.key_shift);
+        stage[2 * u + 1] = (uint32_t)(mine[e] & low);  // position << 1 | strand (sequences here are far below 2^31)
+      }
+      __syncthreads();
+      // the (value, position, strand) triples leave in order, twelve bytes per thread and store
+      const uint64_t first_out = s_excl;
+      const uint64_t room = first_out < a.out_capacity ? a.out_capacity - first_out : 0;
+      const uint32_t n_out = (uint32_t)(uniq < room ? uniq : room);
+      uint32_t* dst = a.out + 3 * first_out;
+      for (uint32_t u = tid; u < n_out; u += kThreads) {
+        const uint32_t value = stage[2 * u], ps = stage[2 * u + 1];
+        uint32_t* to = dst + 3 * (uint64_t)u;
+        to[0] = value;
+        to[1] = ps >> 1;
+        to[2] = ps & 1u;
       }
     }
-  }
-  // place of every distinct key among the distinct keys: its sorted rank minus the duplicates before it
-  uint32_t upos[kPer];
-  if (ndup <= 64) {
-#pragma unroll
-    for (uint32_t e = 0; e < kPer; ++e) {
-      uint32_t d = 0;
-      for (uint32_t x = 0; x < ndup; ++x) d += dup_rank[x] < rank[e] ? 1u : 0u;
-      upos[e] = rank[e] - d;
-    }
-  } else {  // many repeats (never seen on real sequences): mark the duplicates' ranks and count below each rank
-    uint32_t* is_dup = buf;  // (the grouped keys are no longer needed, the staging area not yet written)
-#pragma unroll
-    for (uint32_t e = 0; e < kBinsPer; ++e) is_dup[tid + e * kThreads] = 0;
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < kPer; ++e)
-      if (rank[e] != ~0u && (rank[e] & 0x80000000u)) is_dup[rank[e] & 0x7FFFFFFFu] = 1;
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < kPer; ++e) {
-      uint32_t d = 0;
-      if (!(rank[e] & 0x80000000u))
-        for (uint32_t x = 0; x < rank[e]; ++x) d += is_dup[x];
-      upos[e] = rank[e] - d;
-    }
-    __syncthreads();
-  }
-  const uint64_t low = (1ull << a.key_shift) - 1;
-#pragma unroll
-  for (uint32_t e = 0; e < kPer; ++e) {
-    if (rank[e] & 0x80000000u) continue;  // beyond the keys, or a duplicate
-    const uint32_t u = upos[e];
-    stage[2 * u] = (uint32_t)(mine[e] >> a.key_shift);
-    stage[2 * u + 1] = (uint32_t)(mine[e] & low);  // position << 1 | strand (sequences here are far below 2^31)
-  }
-  __syncthreads();
-  const uint64_t first_out = s_excl;
-  const uint64_t room = first_out < a.out_capacity ? a.out_capacity - first_out : 0;
-  const uint32_t dwords = 3 * (uint32_t)(uniq < room ? uniq : room);
-  uint32_t* dst = a.out + 3 * first_out;
-  for (uint32_t x = tid; x < dwords; x += kThreads) {  // dword x of the run of (value, position, strand) triples
-    const uint32_t u = x / 3, part = x - 3 * u;
-    const uint32_t ps = stage[2 * u + 1];
-    dst[x] = part == 0 ? stage[2 * u] : part == 1 ? ps >> 1 : ps & 1u;
   }
 }
 
@@ -1573,6 +1654,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
   a.hist = pl.buckets ? (uint32_t*)(ws + pl.o_hist) : nullptr;
   a.fine_shift = pl.fine_shift;
   auto blocks = [](uint64_t items) { return dim3((unsigned)((items + kThreads - 1) / kThreads)); };
+  const uint32_t bin_power = std::min<uint32_t>(2 * b->w, 64);  // value_bin: a window's value is the least of ~2w
   size_t t = 0;
   if (pl.buckets) {  // one sequence: the bookkeeping in one launch, the bucket tables cleared alongside
     SA_HIP_TRY(hipMemsetAsync(ws + pl.o_bucket_zero, 0, pl.bucket_zero_bytes, stream));
@@ -1644,6 +1726,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.n = pl.nseg;
     ea.key_shift = pl.key_shift;
     ea.value_bits = pl.end_bit - pl.key_shift;
+    ea.power = bin_power;
     ea.scan_state = (uint64_t*)(ws + pl.o_bscan);
     ea.ticket = (uint32_t*)(ea.scan_state + pl.nseg);
     ea.n_big = n_big;
@@ -1658,7 +1741,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.seg_hif = ba.seg_hif;
     ea.seg_lokey = ba.seg_lokey;
     ea.seg_span = ba.seg_span;
-    hipLaunchKernelGGL(sort_emit_small, dim3(pl.nseg), dim3(kThreads), 0, stream, ea);
+    hipLaunchKernelGGL(sort_emit_small<kEmitBuckets>, dim3(pl.nseg), dim3(kThreads), 0, stream, ea);
     SA_HIP_TRY(hipGetLastError());
     return SA_OK;
   }
@@ -1673,6 +1756,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.n = b->n;
     ea.key_shift = pl.key_shift;
     ea.value_bits = pl.end_bit - pl.key_shift;
+    ea.power = bin_power;
     ea.scan_state = (uint64_t*)(ws + pl.o_scan_state);
     ea.ticket = (uint32_t*)(ea.scan_state + b->n);
     ea.n_big = n_big;
@@ -1686,7 +1770,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.wbase = wbase;
     ea.chunk = pl.chunk;
     SA_HIP_TRY(hipMemsetAsync(ea.scan_state, 0, ((size_t)b->n + 1) * 8, stream));
-    hipLaunchKernelGGL(sort_emit_small, dim3(b->n), dim3(kThreads), 0, stream, ea);
+    hipLaunchKernelGGL(sort_emit_small<kEmitDirect>, dim3(b->n), dim3(kThreads), 0, stream, ea);
     SA_HIP_TRY(hipGetLastError());
     // sequences of at most kSmallMax windows cannot have more keys: nothing is left to do
     if ((uint64_t)b->max_len - (b->k + b->w - 2) <= kSmallMax) return SA_OK;
@@ -1713,6 +1797,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.n = b->n;
     ea.key_shift = pl.key_shift;
     ea.value_bits = pl.end_bit - pl.key_shift;
+    ea.power = bin_power;
     ea.scan_state = (uint64_t*)(ws + pl.o_scan_state);
     ea.ticket = (uint32_t*)(ea.scan_state + b->n);
     ea.n_big = n_big;
@@ -1721,7 +1806,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.out_off = b->d_out_off;
     ea.status = b->d_status;
     SA_HIP_TRY(hipMemsetAsync(ea.scan_state, 0, ((size_t)b->n + 1) * 8, stream));
-    hipLaunchKernelGGL(sort_emit_small, dim3(b->n), dim3(kThreads), 0, stream, ea);
+    hipLaunchKernelGGL(sort_emit_small<kEmitPacked>, dim3(b->n), dim3(kThreads), 0, stream, ea);
   }
   t = pl.scan32_tmp;
   SA_HIP_TRY(rocprim::exclusive_scan(tmp, t, tiles, tile_base, 0u, (size_t)b->n + 1,
@@ -1736,7 +1821,7 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
       SA_HIP_TRY(rocprim::radix_sort_keys(tmp, t, keys, sorted, (size_t)count, 0u, pl.end_bit, stream));
   } else {
     hipLaunchKernelGGL(sort_small, dim3(b->n), dim3(kThreads), 0, stream, keys, sorted, seg_begin, seg_end,
-                       tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift, n_big);
+                       tile_base, tile_count, pl.key_shift, pl.end_bit - pl.key_shift, bin_power, n_big);
     SA_HIP_TRY(hipGetLastError());
     SA_HIP_TRY(rocprim::segmented_radix_sort_keys(tmp, t, keys, sorted, (unsigned)pl.capacity, b->n,
                                                   seg_begin, big_end, 0u, pl.end_bit, stream));

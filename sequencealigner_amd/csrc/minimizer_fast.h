@@ -148,11 +148,9 @@ struct Fast5 {
 #endif
     uint32_t rf1 = (rfw & ~kTagMask) | 1u;
     uint32_t rc = rcw & ~kTagMask;
-    // (computed in every lane: without this the compiler moves them into a branch on "the minimum expires")
-#ifndef SA_FAST5_HOST
-    asm volatile("" : "+v"(pf_res), "+v"(pc_res), "+v"(rf1), "+v"(rc));
-#endif
-    // the state machine, both strands (src/minimizer_binary.cpp:112-133)
+    // the state machine, both strands (src/minimizer_binary.cpp:112-133): an expiring minimum takes the
+    // re-search result, otherwise the new k-mer replaces a strictly larger minimum
+#ifdef SA_FAST5_HOST
     const bool ef = pf == expiring, ec = pc == expiring;
     const bool lf = b < vf1, lc = y > vc;              // V[j] < forward minimum; V[j] > forward maximum
     const uint32_t nvf = umin(vf1, b), nvc = umax(vc, y);
@@ -160,6 +158,30 @@ struct Fast5 {
     vf1 = ef ? rf1 : nvf;
     pc = ec ? pc_res : (lc ? U : pc);
     vc = ec ? rc : nvc;
+#else
+    // (the two strands interleaved: an instruction that reads a compare's mask needs two others between itself
+    // and the compare, and the compiler fills those slots with s_nop when it orders the strands one after the other)
+    uint32_t nvf, nvc, tpf, tpc;
+    uint64_t mask;
+    asm("v_cmp_ge_u32 vcc, %[b], %[vf]\n\t"            // not (V[j] < forward minimum)
+        "v_cmp_le_u32 %[m], %[y], %[vc]\n\t"           // not (V[j] > forward maximum)
+        "v_min_u32 %[nvf], %[vf], %[b]\n\t"
+        "v_max_u32 %[nvc], %[vc], %[y]\n\t"
+        "v_cndmask_b32 %[tpf], %[u], %[pf], vcc\n\t"
+        "v_cndmask_b32 %[tpc], %[u], %[pc], %[m]\n\t"
+        "v_cmp_eq_u32 vcc, %[ex], %[pf]\n\t"           // the forward minimum expires
+        "v_cmp_eq_u32 %[m], %[ex], %[pc]\n\t"          // the other strand's expires
+        "s_nop 0\n\t"
+        "v_cndmask_b32 %[vf], %[nvf], %[rf1], vcc\n\t"
+        "v_cndmask_b32 %[pf], %[tpf], %[pfr], vcc\n\t"
+        "v_cndmask_b32 %[vc], %[nvc], %[rc], %[m]\n\t"
+        "v_cndmask_b32 %[pc], %[tpc], %[pcr], %[m]"
+        : [vf] "+v"(vf1), [pf] "+v"(pf), [vc] "+v"(vc), [pc] "+v"(pc), [nvf] "=&v"(nvf), [nvc] "=&v"(nvc),
+          [tpf] "=&v"(tpf), [tpc] "=&v"(tpc), [m] "=&s"(mask)
+        : [b] "v"(b), [y] "v"(y), [u] "i"((int)U), [ex] "i"((int)expiring), [rf1] "v"(rf1), [pfr] "v"(pf_res),
+          [rc] "v"(rc), [pcr] "v"(pc_res)
+        : "vcc");
+#endif
     if (!EMIT) return false;
     // the window's tuple (:153-158, 167-172): forward when its value is strictly smaller, position << 1 | strand
     const uint32_t cw = kMaskW - vc;                   // the other strand's own value, tag 0
