@@ -978,10 +978,6 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
           mine[e] = i < count ? a.keys[begin + i] : 0;
         }
       }
-#ifdef SA_EXP_LOADONLY
-      if (mine[0] == 0x1234567 && mine[7] == 1) a.out[0] = 1;
-      continue;
-#endif
       __syncthreads();  // the bin counters are cleared (and, direct, every thread has its keys out of LDS)
       uint32_t bin[kPer];
     #pragma unroll
@@ -1067,58 +1063,12 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
         const uint32_t before = __shfl(dexcl, r >> 5), word = __shfl(dword, r >> 5);
         upos[e] = before + __builtin_popcount(word & ((1u << (r & 31)) - 1u));
       }
-      // this sequence's place among all sequences: look back over the predecessors' counts.  Reads: one wave,
-      // 64 predecessors at a time (blocks finish at different times, most find a prefix within a window or two;
-      // all four waves on 256 predecessors, as below, took 13 % longer)
-#ifdef SA_EXP_NOLOOKBACK
-      if (tid == 0) { s_excl = (uint64_t)s * 1545; a.out_off[s] = s_excl; }
-      if (0) {
-#else
-      if (MODE != kEmitBuckets && tid < 64) {
-#endif
-        const uint32_t lane = tid;
-        if (lane == 0)
-          __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t before = 0;
-        int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
-        uint32_t polls = 0;
-        while (top >= 0) {
-          const int64_t idx = top - lane;
-          uint64_t st = kScanPrefix;  // beyond the first sequence: nothing before it
-          if (idx >= 0) st = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t ready = __ballot((st >> 62) != 0);
-          const uint64_t final = __ballot((st >> 62) == 2);
-          // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the window
-          // has no prefix and all 64 are ready)
-          const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
-          const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
-          if ((ready & need) != need) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
-              if (lane == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
-              break;
-            }
-            continue;
-          }
-          uint64_t v = (lane <= stop && idx >= 0) ? (st & kScanValue) : 0;
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-          before += v;
-          if (final) break;
-          top -= 64;
-        }
-        if (lane == 0) {
-          if (s != 0)
-            __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_excl = before;
-          a.out_off[s] = before;
-          if (s + 1 == a.n) {
-            a.out_off[a.n] = before + uniq;
-            if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
-          }
-        }
-      }
+      // Reads: the count of distinct keys is published at once, the look-back over the predecessors' counts comes
+      // after the staging below - blocks that started together publish at about the same time, and a block that
+      // looks back right away mostly waits for the slowest of its 64 predecessors.
+      if (MODE != kEmitBuckets && tid == 0)
+        __hip_atomic_store(&a.scan_state[s], (s == 0 ? kScanPrefix : kScanCount) | uniq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       // Buckets of one sequence: all blocks run at once and finish together, nobody has a prefix yet: 256
       // predecessors at a time (wave v takes the 64 predecessors from top - 64 v downwards); whole waves are used
       // up in order until one meets a predecessor that already carries its prefix, or one whose predecessors
@@ -1190,6 +1140,69 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
         stage[2 * u + 1] = (uint32_t)(mine[e] & low);  // position << 1 | strand (sequences here are far below 2^31)
       }
       __syncthreads();
+      // this sequence's place among all sequences: look back over the predecessors' counts.  Reads: one wave,
+      // 64 predecessors at a time (most find a prefix within a window or two; all four waves on 256
+      // predecessors, as for the buckets, took 13 % longer)
+      if (MODE != kEmitBuckets && tid < 64) {
+        const uint32_t lane = tid;
+        uint64_t before = 0;
+        int64_t top = (int64_t)s - 1;  // newest predecessor not yet added
+        uint32_t polls = 0;
+        constexpr int kWin = 1;  // windows of 64 predecessors per poll (four, all loads in flight together, took
+                                 // 10 % longer: what costs is the polling itself)
+        while (top >= 0) {
+          uint64_t st[kWin];
+#pragma unroll
+          for (int q = 0; q < kWin; ++q) {
+            const int64_t idx = top - (64 * q + (int64_t)lane);
+            st[q] = kScanPrefix;  // beyond the first sequence: nothing before it
+            if (idx >= 0) st[q] = __hip_atomic_load(&a.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          bool done = false, stalled = false;
+          uint32_t used = 0;
+#pragma unroll
+          for (int q = 0; q < kWin; ++q) {
+            if (done || stalled) continue;
+            const int64_t idx = top - (64 * q + (int64_t)lane);
+            const uint64_t ready = __ballot((st[q] >> 62) != 0);
+            const uint64_t final = __ballot((st[q] >> 62) == 2);
+            // lanes 0 .. stop are usable when all of them are ready and lane `stop` carries a prefix (or the
+            // window has no prefix and all 64 are ready)
+            const uint32_t stop = final ? (uint32_t)__builtin_ctzll(final) : 63u;
+            const uint64_t need = stop == 63 ? ~0ull : ((2ull << stop) - 1);
+            if ((ready & need) != need) {
+              stalled = true;
+              continue;
+            }
+            uint64_t v = (lane <= stop && idx >= 0) ? (st[q] & kScanValue) : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            before += v;
+            ++used;
+            done = final != 0;
+          }
+          if (done) break;
+          top -= 64 * (int64_t)used;
+          if (stalled) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++polls > (1u << 24)) {  // the predecessors run already and wait for nobody but theirs: a safety net
+              if (lane == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
+              break;
+            }
+          }
+        }
+        if (lane == 0) {
+          if (s != 0)
+            __hip_atomic_store(&a.scan_state[s], kScanPrefix | (before + uniq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_excl = before;
+          a.out_off[s] = before;
+          if (s + 1 == a.n) {
+            a.out_off[a.n] = before + uniq;
+            if (before + uniq > a.out_capacity && a.status) atomicMax(a.status, SA_ERR_CAPACITY);
+          }
+        }
+      }
+      if (MODE != kEmitBuckets) __syncthreads();  // s_excl
       // the (value, position, strand) triples leave in order, twelve bytes per thread and store
       const uint64_t first_out = s_excl;
       const uint64_t room = first_out < a.out_capacity ? a.out_capacity - first_out : 0;
