@@ -447,21 +447,21 @@ __global__ __launch_bounds__(kThreads) void min_run(MinArgs a, uint32_t* n_unres
   if (!M::kExact && other) atomicOr(a.other, 1u);
 }
 
-// Before the exact machine runs a batch again: forget the unresolved chunks and the histogram of the first
-// run (every chunk writes its keys and their number again).
-__global__ void min_redo_reset(uint32_t* n_unresolved, const uint32_t* other, uint32_t* hist, uint32_t hist_words) {
-  if (*other == 0) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *n_unresolved = 0;
-  if (hist)  // (single-sequence calls) the keys counted so far
-    for (uint32_t x = i; x < hist_words; x += gridDim.x * blockDim.x) hist[x] = 0;
-}
-
 // One wave per sequence, only when some chunk's candidate set did not collapse: those chunks take their
 // entry state from the (final) exit state of the chunk before them, in order, and write their keys anew.
 // Lane 0 runs the machine.
+// A batch in which the first run met bytes other than bases runs again on the exact machine: the first fix
+// kernel then only forgets the unresolved chunks and the histogram of the first run (every chunk writes its
+// keys and their number again).
 template <class M>
-__global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, const uint32_t* n_unresolved) {
+__global__ __launch_bounds__(kThreads) void min_fix(MinArgs a, uint32_t* n_unresolved, uint32_t hist_words) {
+  if (!M::kExact && *a.other) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i == 0) *n_unresolved = 0;
+    if (a.hist)  // (single-sequence calls) the keys counted so far
+      for (uint32_t x = i; x < hist_words; x += gridDim.x * kThreads) a.hist[x] = 0;
+    return;
+  }
   if (*n_unresolved == 0) return;
   if (M::kExact && *a.other == 0) return;
   const uint32_t s = (blockIdx.x * kThreads + threadIdx.x) >> 6;
@@ -833,10 +833,9 @@ __global__ __launch_bounds__(kThreads) void sort_small(const uint64_t* keys, uin
 // (reads).  One block per sequence: the counting sort of sort_small, then the block knows its number of
 // distinct keys and needs the number of all sequences before it: a single-pass chained scan with look-back
 // (every block publishes its own count at once and its inclusive prefix as soon as it knows it; a block adds
-// up the counts of its predecessors backwards until it meets one that already has its prefix).  Sequence
-// numbers are handed out by a ticket counter in start order, so a block only ever waits for blocks that
-// already run.  The triples are staged in LDS and leave as one contiguous run: the sorted keys never travel
-// to memory and back.
+// up the counts of its predecessors backwards until it meets one that already has its prefix).  A block
+// takes the sequence of its own number (see the kernel).  The triples are staged in LDS and leave as one
+// contiguous run: the sorted keys never travel to memory and back.
 constexpr uint64_t kScanCount = 1ull << 62, kScanPrefix = 2ull << 62, kScanValue = (1ull << 62) - 1;
 
 struct EmitArgs {
@@ -847,7 +846,6 @@ struct EmitArgs {
   uint32_t key_shift, value_bits;
   uint32_t power;        // exponent of value_bin's distribution function
   uint64_t* scan_state;  // n entries, zeroed: flag << 62 | value
-  uint32_t* ticket;      // zeroed
   const uint32_t* n_big; // sequences with more than kSmallMax keys
   uint64_t out_capacity;
   uint32_t* out;
@@ -884,7 +882,6 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t buf[2 * kSmallMax + kBins / 2];
   __shared__ uint32_t lds[kThreads / 64];
   __shared__ uint32_t distinct[kSmallMax / 32];  // bit r: the key of sorted rank r is the first of its value
-  __shared__ uint32_t s_seq;
   __shared__ uint64_t s_excl;
   __shared__ uint64_t lb_sum[kThreads / 64];   // look-back: per wave, the counts it may add
   __shared__ uint32_t lb_flag[kThreads / 64];  //   bit 0: usable, bit 1: ends at a prefix
@@ -901,21 +898,14 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
   if (MODE != kEmitBuckets && *a.n_big != 0) return;  // a batch with big sequences takes the several-kernel path
   const uint32_t nsegs = MODE == kEmitBuckets ? *a.nseg_used : a.n;
   // Which segment a block takes.  A block waits, in the look-back, for the segments before its own, so those must
-  // belong to blocks that run or have finished.  Buckets (a few hundred blocks): numbers from a ticket counter, in
-  // start order.  Reads: the block's own number - a returning atomic per block on ONE word would bound the
-  // kernel at about 90 blocks per microsecond (it did: 1.1 of 1.8 ms for 10^5 reads).  Every XCD starts its
+  // belong to blocks that run or have finished.  It takes its own number - numbers from a ticket counter, a
+  // returning atomic per block on ONE word, bound the kernel at about 90 blocks per microsecond (1.1 of 1.8 ms
+  // for 10^5 reads, 50 of 66 us for the 4494 bucket numbers of a 4.6 Mbp sequence).  Every XCD starts its
   // share of the blocks in increasing order, so the lowest-numbered unfinished segment always finds a free slot
   // on its XCD (everything before it on that XCD has finished) and needs no other block: the launch cannot stall;
   // the look-back's waits are bounded all the same and fail the call rather than hang.
   for (uint32_t round = 0; round < 1; ++round) {
-    uint32_t s;
-    if (MODE == kEmitBuckets) {
-      if (tid == 0) s_seq = atomicAdd(a.ticket, 1u);
-      __syncthreads();
-      s = s_seq;
-    } else {
-      s = blockIdx.x;
-    }
+    const uint32_t s = blockIdx.x;
     if (s >= nsegs) return;
     {
       if (tid < kSmallMax / 32) distinct[tid] = 0;
@@ -1224,14 +1214,17 @@ __global__ __launch_bounds__(kThreads) void sort_emit_small(EmitArgs a) {
 // device-wide radix sort's twenty-odd, which is what a call on a single genome-sized sequence costs.
 //   (min_run / min_fix count the keys per fine bin - the top kFineBits bits of a key's significant bits -
 //   as they write them)
-//   bucket_plan     one block: exclusive prefix P of the counts (left in place as the scatter's cursors);
+//   bucket_plan     exclusive prefix P of the counts (left in place as the scatter's cursors);
 //                   bucket of a fine bin = P >> 10, so buckets are runs of whole fine bins and hold at most
 //                   kBucketKeys keys plus one fine bin; writes every bucket's key range and fine-bin range
 //   bucket_scatter  moves every key to its fine bin's range (order inside a bin is arbitrary)
 //   bucket_split    only for a bucket beyond kSmallMax keys (one fine bin that holds thousands of keys: a value
 //                   repeated at thousands of positions): sorts it in place in global memory (bitonic network,
 //                   one block) and hands its slices to the bucket numbers its length left unused
+// (2^16 fine bins: with 2^14 the counters' atomics in min_run and bucket_scatter collide four times as often and
+// cost more than bucket_plan saves)
 constexpr uint32_t kFineBits = 16, kFine = 1u << kFineBits;
+constexpr uint32_t kPlanBlocks = 64;  // bucket_plan: 1024 fine bins a block
 constexpr uint32_t kBucketShift = 10, kBucketKeys = 1u << kBucketShift;
 constexpr uint32_t kNoBin = 0xFFFFFFFFu;
 
@@ -1242,9 +1235,11 @@ struct BucketArgs {
   const uint32_t* chunk_count;
   uint32_t chunk;
   uint32_t fine_shift;
-  uint32_t* hist;           // kFine counters, zeroed; after bucket_plan: exclusive prefix / cursors
+  uint32_t* hist;           // the fine bins' counters, zeroed; after bucket_plan: exclusive prefix / cursors
   uint32_t nseg;            // bucket numbers 0 .. nseg - 1 (more than the keys can fill)
   uint32_t key_shift;       // (the chunks hold raw keys)
+  uint32_t* plan;           // bucket_plan's exchange between its blocks: 3 * kPlanBlocks + 1 words, zeroed
+  int* status;
   uint32_t* nseg_used;      // bucket numbers the keys of this call reach: (count >> kBucketShift) + 1
   uint32_t* seg_begin;      // all zeroed before bucket_plan
   uint32_t* seg_end;
@@ -1254,81 +1249,150 @@ struct BucketArgs {
   uint64_t* seg_span;
 };
 
+// kPlanBlocks blocks, all resident at once (far fewer than the GPU has CUs): every block sums its 1024 fine
+// bins and publishes the sum with its last non-empty bin, waits until all blocks have done so (a bounded wait;
+// the call fails rather than hangs), and then knows where its bins' keys start.
 __global__ __launch_bounds__(kThreads) void bucket_plan(BucketArgs a) {
+  constexpr uint32_t kPer = 4, kOwn = kPer * kThreads;
+  static_assert(kOwn * kPlanBlocks == kFine && kThreads == 256 && kPlanBlocks == 64, "fine_slot's layout, one wave reads the blocks' sums");
+  __shared__ uint32_t cnt[kOwn];  // the block's counters in bin order, later their exclusive prefixes
   __shared__ uint32_t lds[kThreads / 64];
   __shared__ uint32_t last_start[kThreads], last_bin[kThreads];
-  constexpr uint32_t kPer = kFine / kThreads;
-  static_assert(kPer == 256 && kThreads == 256, "fine_slot's transposition");
-  const uint32_t tid = threadIdx.x, base = tid * kPer;
-  // thread t owns the fine bins base .. base + 255, stored at e * 256 + t
-  uint32_t sum = 0, lb = kNoBin, ls = 0;
-  for (uint32_t e0 = 0; e0 < kPer; e0 += 32) {  // 32 loads in flight at a time
-    uint32_t cs[32];
+  __shared__ uint32_t last_owner;  // 1 + the last thread that owns a non-empty fine bin
+  __shared__ uint32_t wave_owner[kThreads / 64];  // the same per wave
+  __shared__ uint32_t s_base, s_total, s_prev, s_prev_start, s_is_last;
+  const uint32_t tid = threadIdx.x, blk = blockIdx.x, lane = tid & 63;
+  uint32_t* plan_total = a.plan;
+  uint32_t* plan_lastbin = a.plan + kPlanBlocks;    // 1 + the block's last non-empty bin, 0: none
+  uint32_t* plan_laststart = a.plan + 2 * kPlanBlocks;  // that bin's first key, counted from the block's first
+  uint32_t* plan_arrived = a.plan + 3 * kPlanBlocks;
+  if (tid == 0) last_owner = 0;
+  {  // bin blk * 1024 + i * 256 + e lives in word e * 256 + 4 * blk + i
+    const uint4 v = *reinterpret_cast<const uint4*>(a.hist + tid * 256 + 4 * blk);
+    cnt[tid] = v.x;
+    cnt[256 + tid] = v.y;
+    cnt[512 + tid] = v.z;
+    cnt[768 + tid] = v.w;
+  }
+  __syncthreads();
+  // thread t owns the block's bins 4t .. 4t + 3
+  const uint32_t first = blk * kOwn + tid * kPer;
+  uint32_t cs[kPer], sum = 0, lb = kNoBin, ls = 0;
 #pragma unroll
-    for (uint32_t x = 0; x < 32; ++x) cs[x] = a.hist[(e0 + x) * kThreads + tid];
-#pragma unroll
-    for (uint32_t x = 0; x < 32; ++x) {
-      if (cs[x]) {
-        lb = base + e0 + x;
-        ls = sum;  // (relative to the thread's first key)
-      }
-      sum += cs[x];
+  for (uint32_t x = 0; x < kPer; ++x) {
+    cs[x] = cnt[tid * kPer + x];
+    if (cs[x]) {
+      lb = first + x;
+      ls = sum;  // (relative to the thread's first key)
     }
+    sum += cs[x];
   }
   uint32_t excl;
-  const uint32_t total = block_sum(sum, lds, &excl);
+  const uint32_t block_total = block_sum(sum, lds, &excl);
   last_start[tid] = excl + ls;  // start of the thread's last non-empty fine bin, for the threads after it
   last_bin[tid] = lb;
+  const uint64_t owners = __ballot(lb != kNoBin);  // (most bins of the upper half of the value range are empty)
+  if (lane == 0) wave_owner[tid >> 6] = owners ? (tid | 63u) + 1 - (uint32_t)__builtin_clzll(owners) : 0;
+  if (lb != kNoBin) atomicMax(&last_owner, tid + 1);
   __syncthreads();
-  uint32_t prev = kNoBin, prev_start = 0;  // the non-empty fine bin before this thread's first one
-  for (int t = (int)tid - 1; t >= 0 && prev == kNoBin; --t) {
-    prev = last_bin[t];
-    prev_start = last_start[t];
+  if (tid == 0) {
+    const uint32_t owner = last_owner;
+    plan_total[blk] = block_total;
+    plan_lastbin[blk] = owner ? last_bin[owner - 1] + 1 : 0;
+    plan_laststart[blk] = owner ? last_start[owner - 1] : 0;
+    __threadfence();
+    atomicAdd(plan_arrived, 1u);
   }
-  uint32_t P = excl;
-  for (uint32_t e0 = 0; e0 < kPer; e0 += 32) {  // 32 counters at a time: loads first, then the stores
-    uint32_t cs[32];
-#pragma unroll
-    for (uint32_t x = 0; x < 32; ++x) cs[x] = a.hist[(e0 + x) * kThreads + tid];
-#pragma unroll
-    for (uint32_t x = 0; x < 32; ++x) {
-      const uint32_t f = base + e0 + x;
-      const uint32_t c = cs[x];
-      a.hist[(e0 + x) * kThreads + tid] = P;
-      if (c) {
-        const uint32_t id = P >> kBucketShift;
-        if (prev == kNoBin || (prev_start >> kBucketShift) != id) {  // first fine bin of bucket id
-          a.seg_begin[id] = P;
-          a.seg_lof[id] = f;
-          if (prev != kNoBin) {
-            a.seg_end[prev_start >> kBucketShift] = P;
-            a.seg_hif[prev_start >> kBucketShift] = prev + 1;
-          }
-        }
-        prev = f;
-        prev_start = P;
+  if (tid < 64) {  // the first wave waits for the other blocks and reads what they published
+    uint32_t spins = 0;
+    while (__hip_atomic_load(plan_arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < kPlanBlocks) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) {  // (seconds) never expected: the other blocks did not start
+        if (tid == 0 && a.status) atomicMax(a.status, SA_ERR_HIP);
+        break;
       }
-      P += c;
+    }
+    const uint32_t tot = __hip_atomic_load(plan_total + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lbin = __hip_atomic_load(plan_lastbin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lstart = __hip_atomic_load(plan_laststart + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d);
+      if ((int)lane >= d) inc += t;
+    }
+    const uint32_t base_of_lane = inc - tot;
+    const uint64_t nonempty = __ballot(lbin != 0);
+    const uint64_t before = blk ? nonempty & ((1ull << blk) - 1ull) : 0ull;
+    const uint64_t after = blk < 63 ? nonempty >> (blk + 1) : 0ull;
+    const uint32_t src = before ? 63u - (uint32_t)__builtin_clzll(before) : 0u;
+    const uint32_t p_bin = __shfl(lbin, src), p_start = __shfl(base_of_lane + lstart, src);
+    const uint32_t my_base = __shfl(base_of_lane, blk), all = __shfl(inc, 63);
+    if (tid == 0) {
+      s_base = my_base;
+      s_total = all;
+      s_prev = before ? p_bin - 1 : kNoBin;
+      s_prev_start = before ? p_start : 0;
+      s_is_last = after == 0;
     }
   }
+  __syncthreads();
+  const uint32_t base = s_base, total = s_total;
+  // the non-empty fine bin before this thread's first one: of the nearest owner among the lanes below, else of
+  // the last owner of a wave before, else of a block before
+  uint32_t prev = s_prev, prev_start = s_prev_start;
+  {
+    const uint64_t below = owners & ((1ull << lane) - 1ull);
+    uint32_t owner = below ? (tid & ~63u) + 64 - (uint32_t)__builtin_clzll(below) : 0;  // 1 + its thread
+    for (int wv = (int)(tid >> 6) - 1; wv >= 0 && owner == 0; --wv) owner = wave_owner[wv];
+    if (owner) {
+      prev = last_bin[owner - 1];
+      prev_start = base + last_start[owner - 1];
+    }
+  }
+  uint32_t P = base + excl;
+#pragma unroll
+  for (uint32_t x = 0; x < kPer; ++x) {
+    const uint32_t f = first + x;
+    const uint32_t c = cs[x];
+    cnt[tid * kPer + x] = P;
+    if (c) {
+      const uint32_t id = P >> kBucketShift;
+      if (prev == kNoBin || (prev_start >> kBucketShift) != id) {  // first fine bin of bucket id
+        a.seg_begin[id] = P;
+        a.seg_lof[id] = f;
+        if (prev != kNoBin) {
+          a.seg_end[prev_start >> kBucketShift] = P;
+          a.seg_hif[prev_start >> kBucketShift] = prev + 1;
+        }
+      }
+      prev = f;
+      prev_start = P;
+    }
+    P += c;
+  }
   // the last bucket ends with the keys
-  bool later = false;
-  for (uint32_t t = tid + 1; t < kThreads; ++t) later |= last_bin[t] != kNoBin;
-  if (lb != kNoBin && !later) {
+  if (s_is_last && last_owner == tid + 1) {
     a.seg_end[prev_start >> kBucketShift] = total;
     a.seg_hif[prev_start >> kBucketShift] = prev + 1;
   }
-  if (tid == 0) *a.nseg_used = (total >> kBucketShift) + 1;
+  if (blk == 0 && tid == 0) *a.nseg_used = (total >> kBucketShift) + 1;
+  __syncthreads();
+  *reinterpret_cast<uint4*>(a.hist + tid * 256 + 4 * blk) = make_uint4(cnt[tid], cnt[256 + tid], cnt[512 + tid], cnt[768 + tid]);
 }
 
-// (one wave per chunk of the sequence: chunk c's keys start at key slot c * chunk)
-__global__ __launch_bounds__(kThreads) void bucket_scatter(BucketArgs a) {
+// (chunk c's keys start at key slot c * chunk; `share` lanes per chunk: 16 for chunks of up to 64 windows, which
+// hold about a third as many keys, up to the whole wave)
+__global__ __launch_bounds__(kThreads) void bucket_scatter(BucketArgs a, uint32_t share) {
   const uint32_t nchunks = *a.nchunks, lane = threadIdx.x & 63;
+  const uint32_t per_wave = 64 / share, sub = lane / share, li = lane % share;
   const uint32_t waves = gridDim.x * (kThreads / 64);
-  for (uint32_t c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); c < nchunks; c += waves) {
+  for (uint32_t c0 = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * per_wave; c0 < nchunks; c0 += waves * per_wave) {
+    const uint32_t c = c0 + sub;
+    if (c >= nchunks) continue;
     const uint32_t n = a.chunk_count[c];
     const uint64_t* src = a.keys + (uint64_t)c * a.chunk;
-    for (uint32_t i = lane; i < n; i += 64) {
+    for (uint32_t i = li; i < n; i += share) {
       const uint64_t key = compose_key(src[i], a.key_shift);
       a.grouped[atomicAdd(&a.hist[fine_slot((uint32_t)(key >> a.fine_shift))], 1u)] = key;
     }
@@ -1465,7 +1529,7 @@ struct MinPlan {
   bool buckets;
   uint32_t nseg, fine_shift;
   size_t o_bucket_zero, bucket_zero_bytes;  // one zeroed block: histogram, bucket tables, scan state + ticket
-  size_t o_hist, o_bseg_begin, o_bseg_end, o_bseg_lof, o_bseg_hif, o_bseg_lokey, o_bseg_span, o_bscan;
+  size_t o_hist, o_bseg_begin, o_bseg_end, o_bseg_lof, o_bseg_hif, o_bseg_lokey, o_bseg_span, o_bscan, o_bplan;
 };
 
 // longest single sequence (in windows) that takes the bucketed sort: beyond it a device-wide radix sort is
@@ -1490,12 +1554,15 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
   pl->capacity = total_len > span * n ? total_len - span * n : 1;  // total windows
   if (pl->capacity >= 0xFFFFFFF0ull) return SA_ERR_ARGUMENT;
   // enough chunks to occupy the GPU: about 2048 windows each for large batches (a chunk pays 160 warm-up
-  // steps), 256 or 128 for small ones (one 4.6 Mbp sequence: 130 / 119 / 102 / 125 / 172 us with 32 / 64 / 128 /
-  // 256 / 512)
+  // steps), 256 down to 64 for small ones (one 4.6 Mbp sequence, the whole call: 200 / 185 / 197 / 204 / 202 us
+  // with 64 / 80 / 96 / 112 / 128)
   pl->chunk = (total_len / 2048 >= 65536)  ? 2048
               : (total_len / 1024 >= 65536) ? 1024
               : (total_len / 256 >= 65536)  ? 256
-                                            : 128;
+              : (total_len / 128 >= 65536)  ? 128
+                                            : 64;
+  if (pl->chunk == 64 && total_len / 64 > 65536)  // between the two: one block of chunks per CU
+    pl->chunk = (uint32_t)((total_len / 65536 + 16) / 16 * 16);
   const uint64_t max_windows = max_len > span ? max_len - span : 1;
   // sequences of about one length (reads): equal chunks - the lanes of a wave run in step, a short last chunk
   // idles its lane
@@ -1573,7 +1640,8 @@ int make_min_plan(uint32_t n, uint64_t total_len, uint32_t max_len, uint32_t k, 
     pl->o_bseg_hif = take(ns * 4);
     pl->o_bseg_lokey = take(ns * 8);
     pl->o_bseg_span = take(ns * 8);
-    pl->o_bscan = take((ns + 2) * 8);  // scan state, ticket, buckets in use
+    pl->o_bscan = take((ns + 2) * 8);  // scan state, buckets in use
+    pl->o_bplan = take((3 * kPlanBlocks + 1) * 4);
     pl->bucket_zero_bytes = o - pl->o_bucket_zero;
   }
   pl->o_tmp = take(std::max(std::max(std::max(pl->scan32_tmp, pl->scan64_tmp), pl->scan_chunks_tmp), pl->sort_tmp));
@@ -1697,14 +1765,13 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
                                             : min_run<Machine<0>, 0>;
     hipLaunchKernelGGL(run, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
     auto* fix = long_k ? min_fix<Machine<0, true>> : min_fix<Machine<0>>;
-    hipLaunchKernelGGL(fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
-    // a batch with bytes other than bases runs again on the exact machine (the three kernels return at
+    hipLaunchKernelGGL(fix, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved, kFine);
+    // a batch with bytes other than bases runs again on the exact machine (the two kernels return at
     // once otherwise)
-    hipLaunchKernelGGL(min_redo_reset, dim3(64), dim3(kThreads), 0, stream, n_unresolved, other, a.hist, kFine);
     auto* run_x = long_k ? min_run<MachineX<true>, 0> : min_run<MachineX<false>, 0>;
     auto* fix_x = long_k ? min_fix<MachineX<true>> : min_fix<MachineX<false>>;
     hipLaunchKernelGGL(run_x, blocks(pl.max_chunks), dim3(kThreads), 0, stream, a, n_unresolved);
-    hipLaunchKernelGGL(fix_x, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved);
+    hipLaunchKernelGGL(fix_x, blocks((uint64_t)b->n * 64), dim3(kThreads), 0, stream, a, n_unresolved, kFine);
   } else {
     hipLaunchKernelGGL(dec_run, blocks(b->n), dim3(kThreads), 0, stream, a);
   }
@@ -1727,10 +1794,13 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ba.seg_lokey = (uint64_t*)(ws + pl.o_bseg_lokey);
     ba.seg_span = (uint64_t*)(ws + pl.o_bseg_span);
     ba.nseg_used = (uint32_t*)((uint64_t*)(ws + pl.o_bscan) + pl.nseg + 1);
-    // (a wave per chunk; the scatter is a chain of atomics that return a value)
-    const dim3 sweep((unsigned)std::min<uint64_t>(pl.max_chunks / (kThreads / 64) + 1, 65535));
-    hipLaunchKernelGGL(bucket_plan, dim3(1), dim3(kThreads), 0, stream, ba);
-    hipLaunchKernelGGL(bucket_scatter, sweep, dim3(kThreads), 0, stream, ba);
+    ba.plan = (uint32_t*)(ws + pl.o_bplan);
+    ba.status = b->d_status;
+    // (the scatter is a chain of atomics that return a value)
+    const uint32_t share = pl.chunk <= 64 ? 16 : pl.chunk <= 128 ? 32 : 64;
+    const dim3 sweep((unsigned)std::min<uint64_t>(pl.max_chunks / (kThreads / share) + 1, 65535));
+    hipLaunchKernelGGL(bucket_plan, dim3(kPlanBlocks), dim3(kThreads), 0, stream, ba);
+    hipLaunchKernelGGL(bucket_scatter, sweep, dim3(kThreads), 0, stream, ba, share);
     hipLaunchKernelGGL(bucket_split, dim3(pl.nseg), dim3(kThreads), 0, stream, ba);
     EmitArgs ea{};
     ea.keys = sorted;
@@ -1741,7 +1811,6 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.value_bits = pl.end_bit - pl.key_shift;
     ea.power = bin_power;
     ea.scan_state = (uint64_t*)(ws + pl.o_bscan);
-    ea.ticket = (uint32_t*)(ea.scan_state + pl.nseg);
     ea.n_big = n_big;
     ea.out_capacity = b->out_capacity;
     ea.out = b->d_out;
@@ -1771,7 +1840,6 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.value_bits = pl.end_bit - pl.key_shift;
     ea.power = bin_power;
     ea.scan_state = (uint64_t*)(ws + pl.o_scan_state);
-    ea.ticket = (uint32_t*)(ea.scan_state + b->n);
     ea.n_big = n_big;
     ea.out_capacity = b->out_capacity;
     ea.out = b->d_out;
@@ -1812,7 +1880,6 @@ int sa_minimize_batch_device(int device, void* stream_, const sa_minimize_batch*
     ea.value_bits = pl.end_bit - pl.key_shift;
     ea.power = bin_power;
     ea.scan_state = (uint64_t*)(ws + pl.o_scan_state);
-    ea.ticket = (uint32_t*)(ea.scan_state + b->n);
     ea.n_big = n_big;
     ea.out_capacity = b->out_capacity;
     ea.out = b->d_out;

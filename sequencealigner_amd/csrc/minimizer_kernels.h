@@ -64,8 +64,9 @@ struct MinArgs {
   uint32_t fine_shift;
 };
 
-// where fine bin f's counter lives: transposed, so that bucket_plan, whose thread t owns the bins
-// t * 256 .. t * 256 + 255, reads and writes the array in coalesced lines
+// where fine bin f's counter lives: neighbouring bins (values are dense at the low end) 1 KB apart, which
+// spreads their atomics; bucket_plan's block b owns the bins b * 1024 .. b * 1024 + 1023 and reads and writes
+// them as 256 pieces of 16 bytes (words e * 256 + 4b .. 4b + 3 for e = 0 .. 255)
 __device__ __forceinline__ uint32_t fine_slot(uint32_t f) { return ((f & 255u) << 8) | (f >> 8); }
 
 // forward-strand code of an ASCII base: C0 A1 T2 G3 (either case).  (c >> 1) & 3 gives A0 C1 T2 G3.
