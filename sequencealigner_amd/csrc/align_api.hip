@@ -45,6 +45,7 @@ Options& options() {
     x->no_tables = getenv("SA_NO_TABLES") != nullptr;
     x->coop_c = num("SA_COOP_C", 0);
     x->coop_waves = num("SA_COOP_WAVES", 8192);
+    x->coop_pk = num("SA_COOP_PK", -1);
     x->pk16_k = num("SA_PK16_K", 48);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
@@ -132,13 +133,13 @@ bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
     *bias_out = (uint32_t)bias;
     return true;
   }
-  const long strip = 64 * kWavePkCols;
-  const long q_pad = (Q + strip - 1) / strip * strip;
-  const long lo = (b.type == SA_GLOBAL ? gap * (q_pad + T) : gap * q_pad) + std::min(gap, std::min(mismatch, 0L));
-  const long hi = std::max(match, 0L) * std::min(Q, T);
-  const long bias = 1 - lo;
-  if (hi + bias + (match - gap) + 1 > 0x7FFF) return false;
-  *bias_out = (uint32_t)bias;
+  // Global / Semiglobal: scores relative to per-lane bases (align_wave_pk16.h) - any length, as long as
+  // neighbouring cells differ by little and the scores themselves fit the 24 bits of a boundary entry
+  const long step = std::max(-gap, match - gap);
+  if (step > kWavePkMaxStep || match - mismatch > 4096) return false;
+  const long worst = std::max(std::max(std::labs(match), std::labs(mismatch)), std::labs(gap));
+  if (worst * (Q + T + 2 * 64 * kWavePkCols) >= (1L << 23)) return false;
+  *bias_out = kWavePkCenter;
   return true;
 }
 
@@ -147,7 +148,9 @@ int pk16_strip_rows() {
   return (v == 32 || v == 48 || v == 64) ? (int)v : 48;
 }
 
-Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
+// pk_coop_passes: the caller's workspace holds so few pairs of this batch at a time that the one-wavefront-per-
+// two-pairs kernel would leave most of the GPU idle: take the packed cooperative kernel whatever the batch's size
+Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_passes = false) {
   Plan pl{};
   const uint32_t max_q = b.max_qlen ? b.max_qlen : 1, max_t = b.max_tlen ? b.max_tlen : 1;
   uint32_t bias = 0;
@@ -224,26 +227,57 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true) {
       if (!coop_c) coop_c = 8;
       if (coop_opt == 2 || coop_opt == 4 || coop_opt == 8) coop_c = (int)coop_opt;
     }
+    if (!coop_c) coop_c = 8;
+    uint32_t wbias = 0;
+    const bool wpk_ok = !force_i32 && wave_pk16_applicable(b, &wbias);
+    // The packed cooperative kernel (two pairs per wavefront, Global / Semiglobal): when the 32-bit one cannot
+    // give every strip of the batch a SIMD of its own the fill is bound by throughput, and the packed form
+    // needs about half the instructions per cell.  Fewer pairs are bound by the chain of strips and keep the
+    // 32-bit kernel's narrow strips.
+    bool pk_coop = false;
+    if (b.type != SA_LOCAL && wpk_ok && b.n >= 2 && max_q > coop_min_q && allow_coop) {
+      const bool many = (uint64_t)b.n * ((max_q + 511) / 512) > 1024;
+      pk_coop = opt.coop_pk >= 0 ? (opt.coop_pk != 0 && (coop_wanted || pk_coop_passes))
+                                 : ((coop_wanted && many) || (pk_coop_passes && force_coop != 0));
+    }
+    if (pk_coop) {
+      // columns per lane: 8, 10, 12 or 16 - the width with which the launch's wavefronts spread most evenly over
+      // the SIMDs (time ~ steps x wavefronts on the fullest SIMD x instructions of a step); "coop_c" pins it
+      const uint64_t units = ((uint64_t)b.n + 1) / 2;
+      double best_time = 0;
+      coop_c = 0;
+      for (int c : {8, 10, 12, 16}) {
+        const uint64_t strips = (max_q + 64 * c - 1) / (64 * c);
+        const uint64_t waves = std::min<uint64_t>(units * strips, 8192);
+        const double per_simd = std::ceil(waves / 1024.0);
+        const double time = (max_t + 63.0 + strips * 90.0) * per_simd * (9.0 * c + 30.0) * std::ceil(units * strips / (double)waves);
+        if (!coop_c || time < best_time) {
+          coop_c = c;
+          best_time = time;
+        }
+      }
+      if (coop_opt == 8 || coop_opt == 10 || coop_opt == 12 || coop_opt == 16) coop_c = (int)coop_opt;
+    }
     const uint64_t strips8 = (max_q + 64 * coop_c - 1) / (64 * coop_c);
     // passes of as many pairs as the limit on a pass's wavefronts allows, at least one
     const uint64_t coop_waves = (uint64_t)std::max(64L, std::min(8192L, (long)opt.coop_waves));
-    pl.coop = coop_wanted && strips8 <= coop_waves;
+    pl.coop = (coop_wanted || pk_coop) && strips8 <= coop_waves && strips8 < 65535;
+    pk_coop = pk_coop && pl.coop;
     // A small batch of short queries is bound by the time of one step, not by throughput: 4 or 8 columns
     // per lane instead of 16 put more lanes of the wavefront to work and shorten the step.
     const bool narrow = !pl.coop && max_q <= 512 && b.n <= 4096;
     pl.wave_c = pl.coop ? coop_c : narrow ? (max_q <= 256 ? 4 : 8) : 16;
-    uint32_t wbias = 0;
-    pl.wave_pk = !pl.coop && !narrow && !force_i32 && wave_pk16_applicable(b, &wbias);
+    pl.wave_pk = pk_coop || (!pl.coop && !narrow && wpk_ok);
     const uint32_t strip = 64 * pl.wave_c;
     pl.family = Family::WaveI32;
-    pl.name = pl.coop ? "wave_i32_coop" : pl.wave_pk ? "wave_pk16" : "wave_i32";
+    pl.name = pk_coop ? "wave_pk16_coop" : pl.coop ? "wave_i32_coop" : pl.wave_pk ? "wave_pk16" : "wave_i32";
     pl.K = pl.wave_c;
     pl.bias = wbias;
     pl.nstrips = (max_q + strip - 1) / strip;
     pl.pairs_per_unit = pl.wave_pk ? 2 : 1;
     pl.dirs_unit_stride = (uint64_t)pl.nstrips * (max_t + 64) * 64 *
                           (pl.wave_pk ? 8 : pl.wave_c == 16 ? 4 : pl.wave_c == 8 ? 2 : 1) / 4;
-    if (pl.coop && b.type != SA_LOCAL)  // one dword per lane per 16 / C steps
+    if (pl.coop && !pl.wave_pk && b.type != SA_LOCAL)  // one dword per lane per 16 / C steps
       pl.dirs_unit_stride = (uint64_t)pl.nstrips * (coop_steps_padded(max_t) * pl.wave_c / 16) * 64;
     pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * 2 * (pl.coop ? 2 : 1);  // 64-bit entries
   } else if (pk16_ok) {
@@ -453,6 +487,56 @@ int launch_wave_i32(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, 
   return SA_OK;
 }
 
+// The traceback of the cooperative kernels' long pairs: by one wavefront per segment of target rows
+// (align_wave_segments.h) when the pairs of the pass are few, the state of the segments in the boundary area,
+// which the fill has finished with; else one wavefront per pair.
+template <int MODE, class Fmt>
+int launch_long_traceback(const AlignArgs& a, const WaveCoop& co, size_t brow_words, hipStream_t stream) {
+  const Options& opt = options();
+  // rows per segment: 1024, for targets below 8192 rows 512; from four segments up
+  uint32_t rows = opt.seg_rows > 0 ? (uint32_t)round_up((size_t)opt.seg_rows, 64) : a.max_t >= 8192 ? 1024 : 512;
+  rows = std::max<uint32_t>(rows, (uint32_t)round_up(((size_t)a.max_t + kMaxSegments - 1) / kMaxSegments, 64));
+  const uint32_t nseg = (a.max_t + rows - 1) / rows;
+  const size_t state_words = seg_state_words(a.pairs_in_pass, nseg) + 1;
+  // Worth it when the path spans four segments or more (a Semiglobal path has about as many rows as the
+  // query has columns, however long the target) and the pairs of the pass are too few to fill the GPU with
+  // one wavefront each (400 pairs of 500 x 5000: 0.05 ms that way, 0.19 ms in segments).
+  const uint32_t path_rows = MODE == SA_SEMIGLOBAL ? std::min(a.max_q, a.max_t) : a.max_t;
+  const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 4 && path_rows >= 4 * rows &&
+                        (a.pairs_in_pass <= 256 || opt.seg_rows > 0) && a.cigar_stride / nseg >= 64 &&
+                        a.cigar_stride / nseg <= 0xFFFFFFFFull && state_words <= brow_words &&
+                        (size_t)a.pairs_in_pass * nseg < ((size_t)1 << 31);
+  Timed tm(stream, 2);
+  if (segments) {
+    SegArgs sg{};
+    sg.rows = rows;
+    sg.nseg = nseg;
+    sg.cap = (uint32_t)(a.cigar_stride / nseg);
+    if (opt.seg_cap > 0 && (uint64_t)opt.seg_cap < sg.cap) sg.cap = (uint32_t)opt.seg_cap;
+    // generous: a segment along the straight line to the end cell has rows + rows * Q / T cells, at worst one
+    // or two per iteration; a guess that runs into the bound costs the segment that time once, not the pair
+    sg.spec_iters = (uint32_t)std::min<uint64_t>(2 * ((uint64_t)rows + (uint64_t)rows * a.max_q / a.max_t) + 64, 1u << 30);
+    sg.pub = reinterpret_cast<uint64_t*>(a.brow);
+    sg.seg_nruns = reinterpret_cast<uint32_t*>(sg.pub + (size_t)a.pairs_in_pass * nseg);
+    sg.redo = sg.seg_nruns + (size_t)a.pairs_in_pass * nseg;
+    sg.ticket = sg.redo + a.pairs_in_pass;
+    sg.abort_flag = co.abort_flag;
+    sg.spin_limit = co.spin_limit;
+    sg.spec_walks = (uint32_t)std::max(0L, std::min(8L, (long)opt.seg_spec));
+    hipLaunchKernelGGL(clear_words, dim3((unsigned)((state_words + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<uint32_t*>(a.brow), (uint32_t)state_words);
+    hipLaunchKernelGGL((traceback_wave_segments<MODE, Fmt>), dim3(a.pairs_in_pass * nseg), dim3(64), 0, stream, a, sg);
+    hipLaunchKernelGGL((stitch_segments<MODE>), dim3(a.pairs_in_pass), dim3(1024), 0, stream, a, sg);
+    AlignArgs ar = a;  // pairs whose segments ran out of room: one wavefront each, from the start
+    ar.tb_only = sg.redo;
+    hipLaunchKernelGGL((traceback_wave<MODE, Fmt>), dim3(a.pairs_in_pass), dim3(64), 0, stream, ar);
+  } else {
+    hipLaunchKernelGGL((traceback_wave<MODE, Fmt>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
+  }
+  SA_HIP_TRY(hipGetLastError());
+  return SA_OK;
+}
+
 template <int MODE, int C>
 int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback) {
   if constexpr (MODE == SA_LOCAL) {
@@ -469,86 +553,57 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
       hipLaunchKernelGGL((fill_wave_coop2<MODE, C>), dim3((unsigned)waves), dim3(64), 0, stream, a, co, tables);
     }
     SA_HIP_TRY(hipGetLastError());
-    if (need_traceback) {
-      // Long pairs: the path is walked by one wavefront per segment of target rows (align_wave_segments.h), the
-      // state of the segments in the boundary area, which the fill has finished with.
-      const Options& opt = options();
-      // rows per segment: 1024, for targets below 8192 rows 512; from four segments up
-      uint32_t rows = opt.seg_rows > 0 ? (uint32_t)round_up((size_t)opt.seg_rows, 64) : a.max_t >= 8192 ? 1024 : 512;
-      rows = std::max<uint32_t>(rows, (uint32_t)round_up(((size_t)a.max_t + kMaxSegments - 1) / kMaxSegments, 64));
-      const uint32_t nseg = (a.max_t + rows - 1) / rows;
-      const size_t state_words = seg_state_words(a.pairs_in_pass, nseg) + 1;
-      // Worth it when the path spans four segments or more (a Semiglobal path has about as many rows as the
-      // query has columns, however long the target) and the pairs of the pass are too few to fill the GPU with
-      // one wavefront each (400 pairs of 500 x 5000: 0.05 ms that way, 0.19 ms in segments).
-      const uint32_t path_rows = MODE == SA_SEMIGLOBAL ? std::min(a.max_q, a.max_t) : a.max_t;
-      const bool segments = !opt.no_segments && a.cigar_runs && nseg >= 4 && path_rows >= 4 * rows &&
-                            (a.pairs_in_pass <= 256 || opt.seg_rows > 0) && a.cigar_stride / nseg >= 64 &&
-                            a.cigar_stride / nseg <= 0xFFFFFFFFull &&
-                            state_words <= (size_t)a.pairs_in_pass * a.brow_unit_stride &&
-                            (size_t)a.pairs_in_pass * nseg < ((size_t)1 << 31);
-      Timed tm(stream, 2);
-      if (segments) {
-        SegArgs sg{};
-        sg.rows = rows;
-        sg.nseg = nseg;
-        sg.cap = (uint32_t)(a.cigar_stride / nseg);
-        if (opt.seg_cap > 0 && (uint64_t)opt.seg_cap < sg.cap) sg.cap = (uint32_t)opt.seg_cap;
-        // generous: a segment along the straight line to the end cell has rows + rows * Q / T cells, at worst one
-        // or two per iteration; a guess that runs into the bound costs the segment that time once, not the pair
-        sg.spec_iters = (uint32_t)std::min<uint64_t>(2 * ((uint64_t)rows + (uint64_t)rows * a.max_q / a.max_t) + 64, 1u << 30);
-        sg.pub = reinterpret_cast<uint64_t*>(a.brow);
-        sg.seg_nruns = reinterpret_cast<uint32_t*>(sg.pub + (size_t)a.pairs_in_pass * nseg);
-        sg.redo = sg.seg_nruns + (size_t)a.pairs_in_pass * nseg;
-        sg.ticket = sg.redo + a.pairs_in_pass;
-        sg.abort_flag = co.abort_flag;
-        sg.spin_limit = co.spin_limit;
-        sg.spec_walks = (uint32_t)std::max(0L, std::min(8L, (long)opt.seg_spec));
-        hipLaunchKernelGGL(clear_words, dim3((unsigned)((state_words + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<uint32_t*>(a.brow), (uint32_t)state_words);
-        hipLaunchKernelGGL((traceback_wave_segments<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass * nseg), dim3(64), 0,
-                           stream, a, sg);
-        hipLaunchKernelGGL((stitch_segments<MODE>), dim3(a.pairs_in_pass), dim3(1024), 0, stream, a, sg);
-        AlignArgs ar = a;  // pairs whose segments ran out of room: one wavefront each, from the start
-        ar.tb_only = sg.redo;
-        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, ar);
-      } else {
-        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtCoop<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
+    if (need_traceback)
+      return launch_long_traceback<MODE, WaveFmtCoop<C>>(a, co, (size_t)a.pairs_in_pass * a.brow_unit_stride, stream);
+    return SA_OK;
+  }
+}
+
+template <int MODE, int C, bool COOP>
+int launch_wave_pk16(const Plan& pl, const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback) {
+  if constexpr (COOP && MODE == SA_LOCAL) {
+    return fail(SA_ERR_ARGUMENT, "packed cooperative kernel chosen for Local");
+  } else {
+    const uint32_t units = (a.pairs_in_pass + 1) / 2;
+    {
+      Timed tm(stream, 1);
+      // score tables inside the kernel (a wavefront whose sequences hold at most four distinct bytes): the
+      // entries (mismatch - gap) and (match - mismatch) << SH must be non-negative bytes
+      const int sh = MODE == SA_LOCAL ? 4 : 0;
+      const uint32_t tables = !options().no_tables && a.mismatch - a.gap >= 0 &&
+                              ((long)(a.mismatch - a.gap) << sh) <= 255 && ((long)(a.match - a.mismatch) << sh) <= 255;
+      if (COOP) {
+        SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
+        // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
+        SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)units * a.brow_unit_stride * 4, stream));
       }
-      SA_HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL((fill_wave_pk16<MODE, C, COOP>), dim3(COOP ? units * a.nstrips : units), dim3(64), 0, stream,
+                         a, co, pl.bias, tables);
+    }
+    SA_HIP_TRY(hipGetLastError());
+    if (need_traceback) {
+      if constexpr (COOP) {
+        return launch_long_traceback<MODE, WaveFmtPk16<C>>(a, co, (size_t)units * a.brow_unit_stride, stream);
+      } else {
+        Timed tm(stream, 2);
+        hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16<C>>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
+        SA_HIP_TRY(hipGetLastError());
+      }
     }
     return SA_OK;
   }
 }
 
 template <int MODE>
-int launch_wave_pk16(const Plan& pl, const AlignArgs& a, hipStream_t stream, bool need_traceback) {
-  {
-    Timed tm(stream, 1);
-    // score tables inside the kernel (a wavefront whose sequences hold at most four distinct bytes): the
-    // entries (mismatch - gap) and (match - mismatch) << SH must be non-negative bytes
-    const int sh = MODE == SA_LOCAL ? 4 : 0;
-    const uint32_t tables = !options().no_tables && a.mismatch - a.gap >= 0 &&
-                            ((long)(a.mismatch - a.gap) << sh) <= 255 && ((long)(a.match - a.mismatch) << sh) <= 255;
-    hipLaunchKernelGGL((fill_wave_pk16<MODE>), dim3((a.pairs_in_pass + 1) / 2), dim3(64), 0, stream, a,
-                       pl.bias, tables);
-  }
-  SA_HIP_TRY(hipGetLastError());
-  if (need_traceback) {
-    {
-      Timed tm(stream, 2);
-      hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16>), dim3(a.pairs_in_pass), dim3(64), 0, stream, a);
-    }
-    SA_HIP_TRY(hipGetLastError());
-  }
-  return SA_OK;
-}
-
-template <int MODE>
 int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t* qpk, uint32_t* tpk,
                 AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
-  if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE>(pl, a, stream, need_tb);
+  if (pl.family == Family::WaveI32 && pl.wave_pk && pl.coop)
+    return pl.wave_c == 8    ? launch_wave_pk16<MODE, 8, true>(pl, a, co, stream, need_tb)
+           : pl.wave_c == 10 ? launch_wave_pk16<MODE, 10, true>(pl, a, co, stream, need_tb)
+           : pl.wave_c == 12 ? launch_wave_pk16<MODE, 12, true>(pl, a, co, stream, need_tb)
+                             : launch_wave_pk16<MODE, 16, true>(pl, a, co, stream, need_tb);
+  if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE, 16, false>(pl, a, co, stream, need_tb);
   if (pl.family == Family::WaveI32 && pl.coop && MODE != SA_LOCAL)
     return pl.wave_c == 2   ? launch_wave_coop2<MODE, 2>(a, co, stream, need_tb)
            : pl.wave_c == 4 ? launch_wave_coop2<MODE, 4>(a, co, stream, need_tb)
@@ -589,6 +644,7 @@ int sa_set_option(const char* name, long value) {
     std::atomic<long>* slot;
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"coop_waves", &o.coop_waves},
+               {"coop_pk", &o.coop_pk},
                {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
@@ -875,7 +931,7 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     // Wavefronts of one pass.  They need not all be resident: strips take their numbers from a ticket counter in
     // start order, so a strip only ever waits for strips that already run.
     const size_t coop_waves = (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
-    const size_t cap = std::max<size_t>(1, coop_waves / pl.nstrips);
+    const size_t cap = std::max<size_t>(1, coop_waves / pl.nstrips) * pl.pairs_per_unit;
     if (pairs_per_pass > cap) pairs_per_pass = cap;
   }
   a.nstrips = pl.nstrips;

@@ -29,8 +29,25 @@
 // pairs' "symbols equal ? match - mismatch : 0" and one three-operand add forms the diagonal candidates:
 // 9 instructions for two cells instead of 11.  Other pairs compare the symbols as described above.
 //
-// Preconditions (checked on the host): gap <= 0, mismatch <= match, gap <= match, every value of the
-// padded matrix within the 15-bit window (Local: gap < 0, mismatch < 0, an 11-bit window).
+// Global and Semiglobal keep every lane's scores RELATIVE to a base of the lane's own (two 32-bit numbers, one
+// per pair): a stored half is S(x - base).  The values a lane holds at one time - 16 neighbouring columns of
+// one row, the value handed over by the lane below, the candidates formed from them - lie within a few dozen
+// times D = max(-gap, match - gap, match - mismatch) of each other, whatever the length of the sequences, since
+// neighbouring cells of the matrix differ by at most D.  Every 64 steps a lane moves its base to the value of
+// its first column (one packed subtraction per register), and a value from the lane below is brought to the
+// lane's own base with one packed addition per step (the difference of the two bases, renewed with them).  So
+// sums, maxima and the direction flags are those of the 32-bit kernel for pairs of any length; only the values
+// that leave the registers - the boundary column between strips, the scores at the pairs' last column - are
+// made absolute again (base + relative value) by the lane that holds them.  Local keeps absolute scores (its
+// clamp at zero needs them) and with them its bound on the score.
+//
+// COOP: one wavefront per (two pairs, strip), all strips of the launch resident at once, strip numbers from a
+// ticket counter; the boundary column goes through memory 16 rows at a time as 64-bit entries {tag of the
+// writing strip, both pairs' values as 24-bit numbers}, written and polled with single device-scope accesses
+// (the protocol of align_wave_i32.h).  For the few long pairs that cannot fill the GPU with a wavefront each.
+//
+// Preconditions (checked on the host): gap <= 0, mismatch <= match, gap <= match; Global / Semiglobal:
+// D <= 64 and every score within 24 bits; Local: gap < 0, mismatch < 0, every value within an 11-bit window.
 #ifndef SA_ALIGN_WAVE_PK16_H
 #define SA_ALIGN_WAVE_PK16_H
 
@@ -39,13 +56,16 @@
 
 namespace sa {
 
-constexpr int kWavePkCols = 16;  // query columns per lane
+constexpr int kWavePkCols = 16;  // query columns per lane (the cooperative form also runs narrower strips)
+constexpr uint32_t kWavePkCenter = 0x4000;  // Global / Semiglobal: a lane's values stay around S(base) = this
+constexpr long kWavePkMaxStep = 64;         // ... for scorings with D up to this
 
 // Direction storage: per (strip, step, lane) one uint2 - .x cells 0-7, .y cells 8-15 of the lane's
 // columns; byte h = "left candidate != m" of pair h, byte 2+h = "diag candidate != m", bit = cell % 8.
 //   word[(s * nsteps + st) * 64 + L],  st = i + L,  nsteps = max_t + 64.
+template <int C_>
 struct WaveFmtPk16 {
-  static constexpr int C = kWavePkCols;
+  static constexpr int C = C_;
   using word_t = uint2;
   static constexpr uint32_t kTileSteps = 64;
   static constexpr uint32_t kStepsPerWord = 1;
@@ -60,16 +80,38 @@ struct WaveFmtPk16 {
   }
 };
 
-template <int MODE>
-__global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias, uint32_t tables) {
-  constexpr int C = kWavePkCols;
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// boundary entries of the relative form: tag << 48 | pair B's value << 24 | pair A's value (24-bit numbers)
+__device__ __forceinline__ uint64_t wave_pk_entry(uint32_t tag, int va, int vb) {
+  return ((uint64_t)tag << 48) | ((uint64_t)((uint32_t)vb & 0xFFFFFFu) << 24) | ((uint32_t)va & 0xFFFFFFu);
+}
+__device__ __forceinline__ int wave_pk_entry_a(uint64_t e) { return (int)((uint32_t)e << 8) >> 8; }
+__device__ __forceinline__ int wave_pk_entry_b(uint64_t e) { return (int)((uint32_t)(e >> 24) << 8) >> 8; }
+
+template <int MODE, int C, bool COOP>
+__global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, uint32_t bias, uint32_t tables) {
+  static_assert(C <= 16 && C % 2 == 0, "one uint2 of flags per step");
+  static_assert(!(COOP && MODE == SA_LOCAL), "the cooperative form is Global / Semiglobal only");
+  constexpr bool REL = MODE != SA_LOCAL;  // scores relative to the lane's bases
   constexpr int SH = (MODE == SA_LOCAL) ? 4 : 0;
   constexpr uint32_t STRIP = 64 * C;
+  constexpr uint32_t NB = COOP ? 16 : 64;  // steps per batch = rows per hand-over between strips
   // per target position (index = position & 255): both pairs' symbols in .x, or the pairs' table words
   __shared__ uint2 tring[256];
   __shared__ uint32_t seen[64];  // byte values that occur in the wavefront's sequences; then their codes
   const uint32_t lane = threadIdx.x;
-  const uint32_t unit = blockIdx.x;
+  uint32_t unit = blockIdx.x, s_mine = 0;
+  if (COOP) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(co.ticket, 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    unit = ticket / a.nstrips;
+    s_mine = ticket % a.nstrips;
+  }
   const uint32_t plA = 2 * unit, plB = plA + 1;
   if (plA >= a.pairs_in_pass) return;
   const bool hasB = plB < a.pairs_in_pass;
@@ -91,9 +133,18 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
   int bestA = 0, bestB = 0, finalA = 0, finalB = 0;
   uint32_t biA = 0, biB = 0, brA = 0, brB = 0;
 
+  // where each pair's last column lives (a pair without cells never matches a strip)
+  const uint32_t lastA = QA ? QA - 1 : 0, lastB = QB ? QB - 1 : 0;
+  const uint32_t stripA = (QA && TA) ? lastA / STRIP : ~0u, stripB = (QB && TB) ? lastB / STRIP : ~0u;
+  if (COOP && s_mine != 0 && s_mine != stripA && s_mine != stripB && s_mine >= (Q + STRIP - 1) / STRIP) return;
+
   if (Q != 0 && T != 0) {
     const uint32_t G = kGuard2;
     auto SG = [&](int v) -> uint32_t { return rep2((uint32_t)((int)bias + v) << SH) | G; };
+    // the two pairs' values, each relative to its own base (REL)
+    auto S2 = [&](int va, int vb) -> uint32_t {
+      return (((uint32_t)((int)bias + va)) & 0x7FFFu) | ((((uint32_t)((int)bias + vb)) & 0x7FFFu) << 16) | G;
+    };
     const uint32_t gsub2 = rep2((uint32_t)(-gap) << SH);                                  // |gap|
     const uint32_t mg2 = rep2((uint32_t)(a.match - gap) << SH);                           // match - gap >= 0
     const uint32_t negdelta2 = rep2(((uint32_t)(a.mismatch - a.match) << SH) & 0xFFFFu);  // mod 2^16
@@ -101,11 +152,9 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
     const uint32_t one2 = 0x00010001u;
     const uint32_t nstrips_p = (Q + STRIP - 1) / STRIP;
     uint2* dirs = reinterpret_cast<uint2*>(a.dirs + (uint64_t)unit * a.dirs_unit_stride);
-    uint64_t* bcol = reinterpret_cast<uint64_t*>(a.brow + (uint64_t)unit * a.brow_unit_stride);
+    uint64_t* bbase = reinterpret_cast<uint64_t*>(a.brow + (uint64_t)unit * a.brow_unit_stride);
+    const uint64_t bhalf = a.brow_unit_stride / 4;  // COOP: two columns of entries, used in turn
     const uint32_t nsteps = a.max_t + 64;
-    // where each pair's last column lives (a pair without cells never matches a strip)
-    const uint32_t lastA = QA ? QA - 1 : 0, lastB = QB ? QB - 1 : 0;
-    const uint32_t stripA = (QA && TA) ? lastA / STRIP : ~0u, stripB = (QB && TB) ? lastB / STRIP : ~0u;
     const uint32_t laneA = (lastA % STRIP) / C, regA = lastA % C;
     const uint32_t laneB = (lastB % STRIP) / C, regB = lastB % C;
 
@@ -125,11 +174,19 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
     const uint32_t delta = (uint32_t)(a.match - a.mismatch) << SH;       // tables: a byte
     const uint32_t exg2 = rep2((uint32_t)(a.mismatch - gap) << SH);      // tables: mismatch - gap >= 0
 
-    auto sweep = [&](auto tab_tag) __attribute__((always_inline)) {
+    auto sweep = [&](auto tab_tag) __attribute__((always_inline)) -> bool {
     constexpr bool TAB = decltype(tab_tag)::value;
-    for (uint32_t s = 0; s < nstrips_p; ++s) {
+    const uint32_t s_lo = COOP ? s_mine : 0u;
+    const uint32_t s_hi = COOP ? (s_mine < nstrips_p ? s_mine + 1 : s_mine) : nstrips_p;
+    for (uint32_t s = s_lo; s < s_hi; ++s) {
       const uint32_t c0 = s * STRIP + lane * C;  // this lane's columns are r = c0+1 .. c0+C
       const bool last_strip = (s + 1 == nstrips_p);
+      const uint64_t* bin = COOP ? bbase + ((s + 1) & 1u) * bhalf : bbase;  // COOP: written by strip s - 1 with tag s
+      uint64_t* bcol = COOP ? bbase + (s & 1u) * bhalf : bbase;             //       written here with tag s + 1
+      // REL: the lane's bases, at first the border value left of its first column
+      int baseA = REL ? border_row0<MODE>((int)c0, gap) : 0, baseB = baseA;
+      uint32_t adj2 = 0;                         // REL: (base of the lane below) - (own base), both pairs
+      int b63A = 0, b63B = 0;                    // REL: lane 63's bases
       // query symbols (A | B << 16) or the columns' table selectors; S(H[i-1][column] + gap)
       uint32_t qc[C], Hg[C];
 #pragma unroll
@@ -143,9 +200,9 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
           const uint32_t sb = (c0 + k < QB) ? (uint32_t)qB[c0 + k] : kQueryPad;
           qc[k] = sa | (sb << 16);
         }
-        Hg[k] = SG(border_row0<MODE>((int)(c0 + 1 + k), gap) + gap);
+        Hg[k] = SG(border_row0<MODE>((int)(c0 + 1 + k), gap) + gap - baseA);
       }
-      uint32_t ldiag = SG(border_row0<MODE>((int)c0, gap) + gap);  // S(H[i-1][c0] + gap), lane's first row
+      uint32_t ldiag = SG(border_row0<MODE>((int)c0, gap) + gap - baseA);  // S(H[i-1][c0] + gap), lane's first row
       uint32_t lastcol = 0, bnext = 0, bout = 0;
       // Local: this strip's best cell of the lane, both pairs - S(score) | 15 - column in the low bits of
       // each half (the value of "no cell yet" is S(0)), and the rows they were found in
@@ -173,15 +230,16 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
                                                       ((uint32_t)k == regB ? 0xFFFF0000u : 0u));
       auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const uint32_t j = (st - 1) & 63;
+        const uint32_t j = (st - 1) & (NB - 1);
         const uint2 tc = tc_next;
         if (TAB)
           tc_next = tring[(st - lane) & 255u];  // position of row st + 1 - lane
         else
           tc_next.x = tring[(st - lane) & 255u].x;
-        const uint32_t from_left = (uint32_t)dpp_from_lane_below((int)lastcol);
-        const uint32_t first = (s == 0) ? SG(border_col0<MODE>((int)st, gap) + gap)
-                                        : (uint32_t)__builtin_amdgcn_readlane((int)bnext, j);
+        uint32_t from_left = (uint32_t)dpp_from_lane_below((int)lastcol);
+        if (REL) from_left = pk_add_u16(from_left, adj2);
+        const uint32_t first = (!REL && s == 0) ? SG(border_col0<MODE>((int)st, gap) + gap)
+                                                : (uint32_t)__builtin_amdgcn_readlane((int)bnext, j);
         const uint32_t recv = lane == 0 ? first : from_left;
         const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
         if (FULL || (st > lane && i <= T)) {
@@ -249,7 +307,7 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
             for (int k = 0; k < C; ++k) pick = and_or(Hg[k], pick_mask[k], pick);
             const uint32_t pickA = pick, pickB = pick;
             if (s == stripA && lane == laneA && i <= TA) {
-              const int v = (int)(pickA & 0x7FFFu) - (int)bias - gap;
+              const int v = (int)(pickA & 0x7FFFu) - (int)bias - gap + baseA;
               if (MODE == SA_SEMIGLOBAL && v > bestA) {  // src/alignment.cpp:87-92, rows in increasing order
                 bestA = v;
                 biA = i;
@@ -257,7 +315,7 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
               if (MODE == SA_GLOBAL && i == TA) finalA = v;
             }
             if (s == stripB && lane == laneB && i <= TB) {
-              const int v = (int)((pickB >> 16) & 0x7FFFu) - (int)bias - gap;
+              const int v = (int)((pickB >> 16) & 0x7FFFu) - (int)bias - gap + baseB;
               if (MODE == SA_SEMIGLOBAL && v > bestB) {
                 bestB = v;
                 biB = i;
@@ -266,34 +324,77 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
             }
           }
         }
-        // lane 63 finished row st - 63 of the strip's last column: collect 64 of them, store coalesced
+        // lane 63 finished row st - 63 of the strip's last column: collect NB of them, store coalesced
         if (!last_strip && (FULL || st >= 64)) {
           const uint32_t v63 = (uint32_t)__builtin_amdgcn_readlane((int)lastcol, 63);
           const uint32_t row = st - 63;  // 1 ..
           const uint32_t slot = (row - 1) & 63;
           bout = lane == slot ? v63 : bout;
-          if (slot == 63 || row == T) {
-            const uint32_t base = row - slot;  // first row held in bout
-            if (base + lane <= row)
-              __hip_atomic_store(&bcol[base + lane], (uint64_t)bout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((slot & (NB - 1)) == NB - 1 || row == T) {
+            const uint32_t first_slot = slot & ~(NB - 1);  // rows of this hand-over: slots first_slot .. slot
+            const uint32_t base = row - slot;              // row held by slot 0
+            if (lane >= first_slot && lane <= slot) {
+              uint64_t e = (uint64_t)bout;
+              if (REL)  // absolute again: lane 63's bases
+                e = wave_pk_entry(s + 1, (int)(bout & 0x7FFFu) - (int)bias + b63A,
+                                  (int)((bout >> 16) & 0x7FFFu) - (int)bias + b63B);
+              __hip_atomic_store(&bcol[base + lane], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
       };
-      for (uint32_t b0 = 1; b0 <= steps; b0 += 64) {  // batches of 64 steps
-        {
-          const uint32_t pos = b0 + lane;  // target positions b0 .. b0+63
+      for (uint32_t b0 = 1; b0 <= steps; b0 += NB) {  // batches of NB steps
+        if (lane < NB) {
+          const uint32_t pos = b0 + lane;  // target positions b0 .. b0 + NB - 1
           tring[pos & 255u] = tsym(pos);
         }
-        if (s > 0) {  // rows b0 .. b0+63 of the previous strip's last column (written by this wave)
+        uint64_t entry = 0;
+        if (s > 0) {  // rows b0 .. b0 + NB - 1 of the previous strip's last column
           const uint32_t row = b0 + lane;
-          bnext = row <= T ? (uint32_t)__hip_atomic_load(&bcol[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                           : 0u;
+          const bool want = lane < NB && row <= T;
+          entry = want ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          if (COOP) {  // (bounded) until all of them carry this strip's tag
+            for (uint32_t polls = 0; !__all(!want || (uint32_t)(entry >> 48) == s); ++polls) {
+              __builtin_amdgcn_s_sleep(1);
+              if (polls >= co.spin_limit ||
+                  ((polls & 1023u) == 1023u && __hip_atomic_load(co.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+              }
+              entry = want ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+          }
+          if (!REL) bnext = (uint32_t)entry;
+        }
+        if (REL) {
+          if ((b0 & 63u) == 1u) {
+            // every 64 steps: the lane's bases move to the value of its first column; what the registers hold
+            // follows, and so do the values of lane 63 collected for the next strip
+            const int dA = (int)(Hg[0] & 0x7FFFu) - (int)bias, dB = (int)((Hg[0] >> 16) & 0x7FFFu) - (int)bias;
+            const uint32_t d2 = ((uint32_t)dA & 0xFFFFu) | ((uint32_t)dB << 16);
+#pragma unroll
+            for (int k = 0; k < C; ++k) Hg[k] = pk_sub_u16(Hg[k], d2);
+            ldiag = pk_sub_u16(ldiag, d2);
+            lastcol = pk_sub_u16(lastcol, d2);
+            baseA += dA;
+            baseB += dB;
+            bout = pk_sub_u16(bout, (uint32_t)__builtin_amdgcn_readlane((int)d2, 63));
+            b63A = __builtin_amdgcn_readlane(baseA, 63);
+            b63B = __builtin_amdgcn_readlane(baseB, 63);
+            adj2 = ((uint32_t)(dpp_from_lane_below(baseA) - baseA) & 0xFFFFu) |
+                   ((uint32_t)(dpp_from_lane_below(baseB) - baseB) << 16);
+          }
+          // lane 0's left values of the batch, relative to lane 0's bases
+          const int b0A = __builtin_amdgcn_readfirstlane(baseA), b0B = __builtin_amdgcn_readfirstlane(baseB);
+          const int left0 = border_col0<MODE>((int)(b0 + lane), gap) + gap;
+          bnext = s == 0 ? S2(left0 - b0A, left0 - b0B)
+                         : S2(wave_pk_entry_a(entry) - b0A, wave_pk_entry_b(entry) - b0B);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, so that no step has to wait on it
-        if (b0 >= 64 && b0 + 63 <= T) {
-          for (uint32_t x = 0; x < 64; ++x) step(b0 + x, std::true_type{});
+        if (b0 >= 64 && b0 + NB - 1 <= T) {
+          for (uint32_t x = 0; x < NB; ++x) step(b0 + x, std::true_type{});
         } else {
-          const uint32_t e = b0 + 63 < steps ? b0 + 63 : steps;
+          const uint32_t e = b0 + NB - 1 < steps ? b0 + NB - 1 : steps;
           for (uint32_t st = b0; st <= e; ++st) step(st, std::false_type{});
         }
       }
@@ -311,11 +412,9 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
         }
       }
     }
+    return true;
     };
-    if (use_tab)
-      sweep(std::true_type{});
-    else
-      sweep(std::false_type{});
+    if (!(use_tab ? sweep(std::true_type{}) : sweep(std::false_type{}))) return;  // gave up waiting
     if (MODE == SA_LOCAL) {  // the lanes' candidates: highest score, smallest row, smallest column
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -349,6 +448,10 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, uint32_t bias,
     if (h == 1 && !hasB) break;
     const uint32_t pl = h ? plB : plA, p = h ? pB : pA;
     const uint32_t Qh = h ? QB : QA, Th = h ? TB : TA;
+    if (COOP) {  // the strip with the pair's last column knows its result (a pair without cells: strip 0)
+      const uint32_t owner = h ? stripB : stripA;
+      if (s_mine != (owner == ~0u ? 0u : owner)) continue;
+    }
     const int best = h ? bestB : bestA, fin = h ? finalB : finalA;
     uint32_t bi = h ? biB : biA, br = Qh;
     int score;

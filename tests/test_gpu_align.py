@@ -39,10 +39,13 @@ def _force_family(name):
     """Pins the kernel family the dispatcher may choose ("lane": the inter-pair lane kernels, packed
     16-bit where exact, else 32-bit; "wave": one pair per wavefront); None restores automatic choice."""
     from sequencealigner_amd import capi
-    family, coop, i32 = 0, -1, 0
+    family, coop, i32, coop_pk = 0, -1, 0, -1
     if name == "wave32":    # one wave per pair, 32-bit scores only
         i32 = 1
         name = "wave"
+    if name == "cooppk":    # as "coop", in the packed form (two pairs per wave) wherever that applies
+        coop_pk = 1
+        name = "coop"
     if name == "coop":      # wavefront kernels, one wave per (pair, strip) wherever the batch allows it
         family, coop = 2, 1
     elif name == "wave":    # wavefront kernels, one wave per pair
@@ -52,9 +55,10 @@ def _force_family(name):
     capi.set_option("force_family", family)
     capi.set_option("force_coop", coop)
     capi.set_option("force_i32", i32)
+    capi.set_option("coop_pk", coop_pk)
 
 
-@pytest.fixture(params=["auto", "lane", "wave", "wave32", "coop"])
+@pytest.fixture(params=["auto", "lane", "wave", "wave32", "coop", "cooppk"])
 def family(request):
     _force_family(None if request.param == "auto" else request.param)
     yield request.param
@@ -279,7 +283,7 @@ def test_full_size_properties():
     assert ((tb + t_used) <= 300).all()
 
 
-@pytest.fixture(params=["wave", "wave32", "coop"])
+@pytest.fixture(params=["wave", "wave32", "coop", "cooppk"])
 def wave_mode(request):
     _force_family(request.param)
     yield request.param
@@ -297,7 +301,8 @@ def test_long_pairs_vs_oracle(oracle, wave_mode):
         assert len(cases) == 6
         b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
         packed = wave_mode == "wave" and typ != 1   # Global / Semiglobal within the 16-bit window
-        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" else
+        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" or (wave_mode == "cooppk" and typ == 1) else
+                                   "wave_pk16_coop" if wave_mode == "cooppk" else
                                    "wave_pk16" if packed else "wave_i32")
         _run_group(cases)
     # one pair with unequal lengths, crossing a strip boundary exactly (2048 columns) and not (2049)
@@ -343,7 +348,7 @@ def test_local_ties_across_strips_vs_oracle(oracle):
     t[15:20] = b"TTTTT"
     want = oracle.align(bytes(q), bytes(t), 1, 1, -1, -1)
     assert want == (5, "5M", 15)
-    for fam in ("wave", "wave32", "coop", "lane", None):
+    for fam in ("wave", "wave32", "coop", "cooppk", "lane", None):
         _force_family(fam)
         try:
             s, c, tb = align.align_batch([bytes(q)], [bytes(t)], 1, 1, -1, -1)
@@ -404,14 +409,15 @@ def _mutated(rng, t, sub, indel):
     return "".join(out) or "A"
 
 
-@pytest.mark.parametrize("cap", [0, 8])
-def test_segmented_traceback_vs_oracle(oracle, cap):
+@pytest.mark.parametrize("cap,packed", [(0, False), (8, False), (0, True), (8, True)])
+def test_segmented_traceback_vs_oracle(oracle, cap, packed):
     """The traceback of long Global / Semiglobal pairs by one wavefront per segment of target rows (speculative
     starts, walked again from the column the segment above lands on, joined afterwards): with 64-row segments
     pairs of a few hundred to a few thousand rows take that path.  Related pairs, unrelated ones (the walks meet
     late or not at all inside a segment), two-letter alphabets (ties), long gaps inside the matrix and along its
     borders, targets far longer than the query and the reverse, pairs of unequal length in one batch.  cap = 8:
-    every segment runs out of room for its runs, which sends the pair to the one-wavefront walk."""
+    every segment runs out of room for its runs, which sends the pair to the one-wavefront walk.  packed: the
+    cooperative kernel with two pairs per wavefront, whose direction words the same walk reads."""
     from sequencealigner_amd import align, capi
     rng = random.Random(2024 + cap)
     batches = []
@@ -437,7 +443,7 @@ def test_segmented_traceback_vs_oracle(oracle, cap):
     gaps.append(("ACGTACGTAC", "T" * 700 + "ACGTACGTAC" + "G" * 900))
     gaps.append(("T" * 700 + "ACGTACGTAC" + "G" * 900, "ACGTACGTAC" * 60))
     batches.append(gaps)
-    _force_family("coop")
+    _force_family("cooppk" if packed else "coop")
     capi.set_option("seg_rows", 64)
     capi.set_option("seg_cap", cap)
     try:
@@ -449,7 +455,7 @@ def test_segmented_traceback_vs_oracle(oracle, cap):
                 if not cases:
                     continue
                 b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
-                assert b.kernel_name() == "wave_i32_coop"
+                assert b.kernel_name() == ("wave_pk16_coop" if packed else "wave_i32_coop")
                 _run_group(cases)
                 n += len(cases)
         assert n > 120

@@ -99,10 +99,10 @@ def test_config3_semiglobal_10k_x_11k_packed_wavefront_kernel(oracle):
     for i in range(3):
         want = oracle.align(bytes(q[i]), bytes(t[i]), 2, 1, -1, -1)
         assert (int(scores[i]), cig[i], 1) == want, i
-    # Left to the dispatcher, 512 long pairs are too few wavefronts for the one-pair-per-wavefront kernels: they
-    # run on the cooperative kernel in passes, with the traceback in segments, and give the same runs.
+    # Left to the dispatcher, 512 long pairs are too few wavefronts for the one-wavefront-per-two-pairs kernel: they
+    # run on its cooperative form (a wavefront per strip) and give the same runs.
     bc = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
-    assert bc.kernel_name() == "wave_i32_coop"
+    assert bc.kernel_name() == "wave_pk16_coop"
     bc.run()
     torch.cuda.synchronize()
     assert np.array_equal(bc.scores(), scores) and np.array_equal(bc.target_begins(), b.target_begins())
@@ -147,3 +147,60 @@ def test_config5_global_100k_x_100k_single_pair(oracle):
     lead = int(runs[0])
     assert int(b.target_begins()[0]) == (3 if (lead & 3) == 3 and (lead >> 2) <= 9 else 1)
     assert score == oracle.score_linear(q, t, 0, 1, -1, -1)
+
+
+@pytest.mark.parametrize("length,target_len,n", [(20_000, 22_000, 6), (40_000, 44_000, 4)])
+def test_long_pairs_on_the_packed_wavefront_kernels(oracle, length, target_len, n):
+    """Global and Semiglobal pairs of 20 kbp x 22 kbp and 40 kbp x 44 kbp (scores down to -40 000 and up to
+    +30 000: far outside 15 bits) on the packed 16-bit wavefront kernel, which keeps every lane's scores relative
+    to a base of its own, in both forms: one wavefront per two pairs, and one per (two pairs, strip).  Every
+    score equals the CPU checker's linear-memory scorer, every CIGAR re-scores to it, consumes the aligned spans
+    and has M on equal and X on unequal symbols; at 20 kbp the first pair of each type equals the CPU checker's
+    full-matrix result verbatim.  Pairs of a batch differ in length (the two pairs of a wavefront then end in
+    different strips), and one of them is unrelated to its target."""
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    rng = np.random.default_rng(length)
+    qs, ts = [], []
+    for p in range(n):
+        t = synth.random_bases(rng, target_len - 700 * p)
+        lead = 900 if p % 2 else 0
+        q = synth.fit_length(rng, synth.edit(rng, t[lead:lead + length], 0.04, 0.03, 0.03), length - 1100 * p)
+        if p == 3:
+            q = synth.random_bases(rng, q.shape[0])
+        qs.append(bytes(q))
+        ts.append(bytes(t))
+    qb, qo = synth.to_blob(qs)
+    tb, to = synth.to_blob(ts)
+    for typ in (0, 2):
+        want = oracle.score_linear_batch(qb, qo, tb, to, typ, 1, -1, -1, 8)
+        assert want.min() < -0x8000 or want.max() > 0x7000 or typ == 2
+        full = oracle.align(qs[0], ts[0], typ, 1, -1, -1) if length <= 20_000 else None
+        for name, coop, pk in (("wave_pk16", 0, -1), ("wave_pk16_coop", 1, 1)):
+            capi.set_option("force_coop", coop)
+            capi.set_option("coop_pk", pk)
+            try:
+                b = align.DeviceAlignBatch(qs, ts, typ, 1, -1, -1)
+                assert b.kernel_name() == name
+                b.run()
+                torch.cuda.synchronize()
+            finally:
+                capi.set_option("force_coop", -1)
+                capi.set_option("coop_pk", -1)
+            scores = b.scores()
+            assert np.array_equal(scores, want), (typ, name)
+            nruns = b.d_nruns[:n].cpu().numpy()
+            runs = b.d_runs.cpu().numpy().view(np.uint32).reshape(n, b.stride)
+            rs, qu, tu = _rescore(runs, nruns, b.stride, 1, -1, -1)
+            assert np.array_equal(rs, scores), (typ, name)
+            for p in range(n):
+                pr = runs[p, b.stride - nruns[p]:]
+                assert (pr[1:] & 3 != pr[:-1] & 3).all()
+                assert int(qu[p]) == len(qs[p])
+                if typ == 0:
+                    assert int(tu[p]) == len(ts[p]) and _walk(pr, qs[p], ts[p], 0, 0) == (len(qs[p]), len(ts[p]))
+                else:
+                    assert 0 < int(tu[p]) <= len(ts[p])
+            if full is not None:
+                assert (int(scores[0]), b.cigars([0])[0], int(b.target_begins()[0])) == full, (typ, name)
+            del b, runs

@@ -1,6 +1,7 @@
 """Directed GPU tests at the range guards of the packed 16-bit kernels.  The dispatcher may use them only while
-every value the DP forms fits their score window (15 bits for Global / Semiglobal; Local's best-cell key leaves
-9 bits in the lane kernel and 11 in the wavefront kernel); one base or one score unit beyond, it must fall back to the 32-bit kernels.  For each guard: a batch whose
+every value the DP forms fits their score window (15 bits for Global / Semiglobal in the lane kernel, a bound on
+the difference of neighbouring cells in the wavefront kernel; Local's best-cell key leaves 9 bits in the lane
+kernel and 11 in the wavefront kernel); one base or one score unit beyond, it must fall back to the 32-bit kernels.  For each guard: a batch whose
 largest admissible value sits exactly at the window edge must run on the packed kernel and equal the CPU
 checker, and the batch one step beyond must run on the 32-bit kernel and equal it too.  Contents that reach the
 extremes: identical sequences (highest scores), sequences without a common symbol (lowest), related random ones."""
@@ -67,24 +68,29 @@ def test_packed_lane_kernel_window_edge(oracle, typ, scheme, T, q_edge):
 
 
 WAVE_CASES = [
-    # Global 1/-3/-3, Q = 2000 (swept as 2048 columns): 3 (2048 + T) + 4 + 2000 + 4 + 1 <= 32767
-    (0, (1, -3, -3), 2000, 8204, "T"),
-    # Semiglobal 13/-3/-3, T = 2100: 3 * 2048 + 4 + 13 Q + 16 + 1 <= 32767
-    (2, (13, -3, -3), 2046, 2100, "Q"),
+    # Global / Semiglobal keep scores relative to per-lane bases: no bound on the length, but neighbouring cells
+    # may differ by at most 64, max(-gap, match - gap) <= 64 ...
+    (0, (1, -3, -63), 1500, 1700, ("scheme", (1, -3, -64))),
+    (2, (7, -3, -57), 1500, 1700, ("scheme", (8, -3, -57))),
+    # ... and absolute scores travel between strips as 24-bit numbers: 1000 (Q + T + 2048) < 2^23
+    (2, (1, -1000, -3), 3000, 3340, ("T", 3341)),
     # Local keeps scores times 16 in 15 bits.  1/-1/-1: bias 2, min(Q, T) + 2 + 2 + 1 <= 2047
-    (1, (1, -1, -1), 2042, 2100, "Q"),
+    (1, (1, -1, -1), 2042, 2100, ("Q", 2043)),
     # Local 2/-3/-2: bias 4, 2 min(Q, T) + 4 + 4 + 1 <= 2047
-    (1, (2, -3, -2), 1500, 1019, "T"),
+    (1, (2, -3, -2), 1500, 1019, ("T", 1020)),
 ]
 
 
-@pytest.mark.parametrize("typ,scheme,Q,T,grow", WAVE_CASES)
-def test_packed_wavefront_kernel_window_edge(oracle, typ, scheme, Q, T, grow):
+@pytest.mark.parametrize("typ,scheme,Q,T,beyond", WAVE_CASES)
+def test_packed_wavefront_kernel_window_edge(oracle, typ, scheme, Q, T, beyond):
     _check(oracle, 2, 0, typ, scheme, Q, T, "wave_pk16", seed=20 + typ)
-    if grow == "T":
-        _check(oracle, 2, 0, typ, scheme, Q, T + 1, "wave_i32", seed=30 + typ)
+    what, value = beyond
+    if what == "scheme":
+        _check(oracle, 2, 0, typ, value, Q, T, "wave_i32", seed=30 + typ)
+    elif what == "T":
+        _check(oracle, 2, 0, typ, scheme, Q, value, "wave_i32", seed=30 + typ)
     else:
-        _check(oracle, 2, 0, typ, scheme, Q + 1, T, "wave_i32", seed=30 + typ)
+        _check(oracle, 2, 0, typ, scheme, value, T, "wave_i32", seed=30 + typ)
 
 
 def test_conditions_the_packed_kernels_never_take(oracle):
