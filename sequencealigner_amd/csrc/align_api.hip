@@ -237,8 +237,11 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
     bool pk_coop = false;
     if (b.type != SA_LOCAL && wpk_ok && b.n >= 2 && max_q > coop_min_q && allow_coop) {
       const bool many = (uint64_t)b.n * ((max_q + 511) / 512) > 1024;
+      // (tools/pkcoop.py, pairs of 10 kbp x 11 kbp: 256 pairs 8.0 ms against 13.4 on the 32-bit cooperative kernel
+      // and 50 with a wavefront per two pairs; 1024 pairs 26 against 47 and 50; 2048 pairs 50 against 93 and 52)
+      const bool few_long = force_coop < 0 && b.n <= 2048 && max_q >= 4096;
       pk_coop = opt.coop_pk >= 0 ? (opt.coop_pk != 0 && (coop_wanted || pk_coop_passes))
-                                 : ((coop_wanted && many) || (pk_coop_passes && force_coop != 0));
+                                 : (((coop_wanted || few_long) && many) || (pk_coop_passes && force_coop != 0));
     }
     if (pk_coop) {
       // columns per lane: 8, 10, 12 or 16 - the width with which the launch's wavefronts spread most evenly over
@@ -771,19 +774,37 @@ size_t blocks_in_a_pass(const Plan& pl, const sa_align_batch& b, size_t workspac
   return blocks_per_pass;
 }
 
+// The plan of a batch over a workspace of this size.  Long pairs need hundreds of megabytes of direction words
+// each: when the workspace holds fewer than 2048 wavefronts' worth of them at a time, the kernel with one
+// wavefront per two pairs would leave most SIMDs idle in every pass, and the batch takes the packed cooperative
+// kernel (a wavefront per strip) whatever its size.
+Plan plan_for_workspace(const sa_align_batch& b, bool allow_coop, size_t workspace_bytes, int device) {
+  Plan pl = make_plan(b, allow_coop);
+  if (allow_coop && pl.family == Family::WaveI32 && pl.wave_pk && !pl.coop && b.type != SA_LOCAL &&
+      workspace_bytes >= pl.bytes_per_block + kFixedWorkspace) {
+    const size_t total_blocks = ((size_t)b.n + pl.pairs_per_block - 1) / pl.pairs_per_block;
+    const size_t per_pass = blocks_in_a_pass(pl, b, workspace_bytes, device);
+    if (per_pass < total_blocks && per_pass * pl.units_per_block < 2048) {
+      const Plan coop = make_plan(b, allow_coop, true);
+      if (coop.coop && coop.wave_pk && workspace_bytes >= coop.bytes_per_block + kFixedWorkspace) pl = coop;
+    }
+  }
+  return pl;
+}
+
 // Pairs of a several-pass batch of the one-wavefront-per-pair kernels that are planned again as a batch of their
 // own (0: none): the last pass's pairs when they are too few to fill the GPU.
 size_t leftover_pairs(const Plan& pl, const sa_align_batch& b, size_t pairs_per_pass, bool static_scratch_call) {
   if (pl.family != Family::WaveI32 || pl.coop || static_scratch_call || b.n <= pairs_per_pass) return 0;
   const size_t rest = b.n % pairs_per_pass;
-  return rest <= 768 ? rest : 0;
+  return rest <= 2048 ? rest : 0;
 }
 
 // Whether align_batch_device would run cooperative kernels (and therefore synchronise the stream) for this batch
 // over a workspace of this size: directly, or for the head or the left-over pairs of a several-pass batch.
 bool batch_synchronises(const sa_align_batch& b, size_t workspace_bytes, int device) {
   if (b.n == 0 || b.type < 0 || b.type > 2) return false;
-  const Plan pl = make_plan(b, true);
+  const Plan pl = plan_for_workspace(b, true, workspace_bytes, device);
   if (pl.coop) return true;
   if (workspace_bytes < pl.bytes_per_block + kFixedWorkspace) return false;  // the call fails before any launch
   const size_t pairs_per_pass = blocks_in_a_pass(pl, b, workspace_bytes, device) * pl.pairs_per_block;
@@ -844,7 +865,7 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
   hipStream_t stream = (hipStream_t)stream_;
 
   // the static-scratch call only enqueues work: never the cooperative kernels, which synchronise the stream
-  const Plan pl = make_plan(*b, !static_scratch_call);
+  const Plan pl = plan_for_workspace(*b, !static_scratch_call, workspace_bytes, device);
   if (static_scratch_call) {
     if (pl.bytes_per_block + kFixedWorkspace > kStaticScratchBytes)
       return fail(SA_ERR_WORKSPACE,

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
   constexpr int SH = (MODE == SA_LOCAL) ? 4 : 0;
   constexpr uint32_t STRIP = 64 * C;
   constexpr uint32_t NB = COOP ? 16 : 64;  // steps per batch = rows per hand-over between strips
-  // per target position (index = position & 255): both pairs' symbols in .x, or the pairs' table words
-  __shared__ uint2 tring[256];
+  // per target position (index = position & 255, and again 256 further on, so that 16 positions from any start
+  // are contiguous): both pairs' symbols in .x, or the pairs' table words
+  __shared__ uint2 tring[512];
   __shared__ uint32_t seen[64];  // byte values that occur in the wavefront's sequences; then their codes
   const uint32_t lane = threadIdx.x;
   uint32_t unit = blockIdx.x, s_mine = 0;
@@ -207,20 +208,36 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
       // Local: this strip's best cell of the lane, both pairs - S(score) | 15 - column in the low bits of
       // each half (the value of "no cell yet" is S(0)), and the rows they were found in
       uint32_t skey = floor2, siA = 0, siB = 0;
-      // both pairs' target symbols at a position; tables: per pair (match - mismatch) in the symbol's byte
-      auto tsym = [&](uint32_t pos) -> uint2 {
-        if (TAB) {
-          const uint32_t wa = pos < TA ? delta << (8 * (uint32_t)codes[tA[pos]]) : 0u;
-          const uint32_t wb = pos < TB ? delta << (8 * (uint32_t)codes[tB[pos]]) : 0u;
-          return make_uint2(wa, wb);
-        }
+      // both pairs' target symbols at a position, as loaded (a position beyond a pair's target: the padding
+      // symbol), and as the steps want them; tables: per pair (match - mismatch) in the symbol's byte
+      auto traw = [&](uint32_t pos) -> uint32_t {
         const uint32_t sa = pos < TA ? (uint32_t)tA[pos] : kTargetPad;
         const uint32_t sb = pos < TB ? (uint32_t)tB[pos] : kTargetPad;
-        return make_uint2(sa | (sb << 16), 0u);
+        return sa | (sb << 16);
       };
-      if (lane == 0) tring[0] = tsym(0);
-      uint2 tc_next = tsym(0);  // lane 0's first row; the other lanes read theirs from the ring
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing stays pending into the step loop
+      auto tconv = [&](uint32_t raw) -> uint2 {
+        if (TAB) {
+          const uint32_t sa = raw & 0xFFFFu, sb = raw >> 16;
+          const uint32_t wa = sa < 256u ? delta << (8 * (uint32_t)codes[sa]) : 0u;
+          const uint32_t wb = sb < 256u ? delta << (8 * (uint32_t)codes[sb]) : 0u;
+          return make_uint2(wa, wb);
+        }
+        return make_uint2(raw, 0u);
+      };
+      // the entries of the previous strip's last column for rows b0 .. b0 + NB - 1
+      auto load_entries = [&](uint32_t b0) -> uint64_t {
+        const uint32_t row = b0 + lane;
+        return (s > 0 && lane < NB && row <= T) ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                : 0ull;
+      };
+      auto ring_put = [&](uint32_t pos, uint2 v) {
+        tring[pos & 255u] = v;
+        tring[(pos & 255u) + 256u] = v;
+      };
+      if (lane == 0) ring_put(0, tconv(traw(0)));
+      // a batch's inputs are fetched one batch ahead, so that no batch starts with a wait for memory
+      uint32_t t_pre = lane < NB ? traw(1 + lane) : 0u;
+      uint64_t e_pre = load_entries(1);
       const uint32_t steps = T + 63;
       uint2* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
       uint32_t pick_mask[C];  // wave-uniform: which half of which column holds a pair's last column
@@ -228,132 +245,153 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
       for (int k = 0; k < C; ++k)
         pick_mask[k] = __builtin_amdgcn_readfirstlane(((uint32_t)k == regA ? 0x0000FFFFu : 0u) |
                                                       ((uint32_t)k == regB ? 0xFFFF0000u : 0u));
-      auto step = [&](uint32_t st, auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const uint32_t j = (st - 1) & (NB - 1);
-        const uint2 tc = tc_next;
-        if (TAB)
-          tc_next = tring[(st - lane) & 255u];  // position of row st + 1 - lane
-        else
-          tc_next.x = tring[(st - lane) & 255u].x;
-        uint32_t from_left = (uint32_t)dpp_from_lane_below((int)lastcol);
-        if (REL) from_left = pk_add_u16(from_left, adj2);
-        const uint32_t first = (!REL && s == 0) ? SG(border_col0<MODE>((int)st, gap) + gap)
-                                                : (uint32_t)__builtin_amdgcn_readlane((int)bnext, j);
-        const uint32_t recv = lane == 0 ? first : from_left;
-        const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
-        if (FULL || (st > lane && i <= T)) {
-          // pass 1 (no dependencies between cells): diagonal candidates from the previous row's values
-          // still held in Hg, already maximised with the "up" candidate
-          uint32_t dc[C], mx[C];
+      // The cells of one step: row i = st - lane of the lane's columns, from the row's target symbols tc and the
+      // value recv handed over from the left; the step's direction words go to dst.
+      // (pick_tag: whether the step may be the one that holds a Global pair's result)
+      auto cells = [&](uint2 tc, uint32_t recv, uint32_t i, uint32_t st, uint2* dst, auto pick_tag)
+                       __attribute__((always_inline)) {
+        constexpr bool PICK = decltype(pick_tag)::value;
+        // pass 1 (no dependencies between cells): diagonal candidates from the previous row's values
+        // still held in Hg, already maximised with the "up" candidate
+        uint32_t dc[C], mx[C];
 #pragma unroll
-          for (int k = 0; k < C; ++k) {
-            const uint32_t diag = k ? Hg[k - 1] : ldiag;
-            if (TAB) {  // S(H + mismatch) + (symbols equal ? match - mismatch : 0), both pairs
-              dc[k] = diag + exg2 + __builtin_amdgcn_perm(tc.y, tc.x, qc[k]);
-            } else {
-              const uint32_t ne = pk_min_u16(tc.x ^ qc[k], one2);  // 1 where the symbols differ
-              dc[k] = pk_mad_u16(ne, negdelta2, diag + mg2);
-            }
-            mx[k] = pk_max_u16(dc[k], Hg[k]);
-            if (MODE == SA_LOCAL) mx[k] = pk_max_u16(mx[k], floor2);
+        for (int k = 0; k < C; ++k) {
+          const uint32_t diag = k ? Hg[k - 1] : ldiag;
+          if (TAB) {  // S(H + mismatch) + (symbols equal ? match - mismatch : 0), both pairs
+            dc[k] = diag + exg2 + __builtin_amdgcn_perm(tc.y, tc.x, qc[k]);
+          } else {
+            const uint32_t ne = pk_min_u16(tc.x ^ qc[k], one2);  // 1 where the symbols differ
+            dc[k] = pk_mad_u16(ne, negdelta2, diag + mg2);
           }
-          // pass 2: the dependent chain along the row (max with the left candidate, then + gap), with the
-          // flag work of the cell before interleaved so that the chain's latencies are covered.  Flags:
-          // candidate - max is negative (bit 15 of the half set) exactly when the candidate is NOT the
-          // maximum; one v_perm turns the four sign bits into four 0x00/0xFF bytes.
-          uint32_t left = recv, acc0 = 0, acc1 = 0, rowkey = 0;
-          auto flags = [&](int k, uint32_t lin) __attribute__((always_inline)) {
-            if (MODE == SA_LOCAL) rowkey = pk_max_u16(rowkey, mx[k] | rep2((uint32_t)(15 - k)));
-            const uint32_t signs =
-                __builtin_amdgcn_perm(pk_sub_u16(dc[k], mx[k]), pk_sub_u16(lin, mx[k]), 0x0B0A0908u);
-            if (k < 8)
-              acc0 = and_or(signs, 0x01010101u << (k & 7), acc0);
-            else
-              acc1 = and_or(signs, 0x01010101u << (k & 7), acc1);
-          };
-          uint32_t lin_prev = recv;
-#pragma unroll
-          for (int k = 0; k < C; ++k) {
-            const uint32_t lin = left;
-            mx[k] = pk_max_u16(mx[k], left);
-            left = mx[k] - gsub2;  // S(H[i][column] + gap)
-            Hg[k] = left;
-            if (k > 0) flags(k - 1, lin_prev);
-            lin_prev = lin;
-          }
-          flags(C - 1, lin_prev);
-          // written once, read once by the traceback: keep it out of the caches
-          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-          __builtin_nontemporal_store(u32x2{acc0, acc1}, reinterpret_cast<u32x2*>(drow + (uint64_t)st * 64));
-          ldiag = recv;
-          lastcol = left;
-          if (MODE == SA_LOCAL) {
-            // a row replaces the strip's candidate only with a strictly larger score: with the low bits of
-            // the old key filled, an equal score never exceeds it
-            const uint32_t old = skey | 0x000F000Fu;
-            const uint32_t now = pk_max_u16(old, rowkey);
-            const uint32_t changed = now ^ old;
-            const bool upA = (changed & 0xFFFFu) != 0, upB = (changed >> 16) != 0;
-            skey = (upA ? now & 0x0000FFFFu : skey & 0x0000FFFFu) | (upB ? now & 0xFFFF0000u : skey & 0xFFFF0000u);
-            siA = upA ? i : siA;
-            siB = upB ? i : siB;
-          }
-          // a pair's last column is in this strip; Global wants it on one step only, the pair's last row
-          if (MODE != SA_LOCAL && (s == stripA || s == stripB) &&
-              (MODE != SA_GLOBAL || (s == stripA && st == TA + laneA) || (s == stripB && st == TB + laneB))) {
-            uint32_t pick = 0;  // low half: pair A's column regA, high half: pair B's column regB
-#pragma unroll
-            for (int k = 0; k < C; ++k) pick = and_or(Hg[k], pick_mask[k], pick);
-            const uint32_t pickA = pick, pickB = pick;
-            if (s == stripA && lane == laneA && i <= TA) {
-              const int v = (int)(pickA & 0x7FFFu) - (int)bias - gap + baseA;
-              if (MODE == SA_SEMIGLOBAL && v > bestA) {  // src/alignment.cpp:87-92, rows in increasing order
-                bestA = v;
-                biA = i;
-              }
-              if (MODE == SA_GLOBAL && i == TA) finalA = v;
-            }
-            if (s == stripB && lane == laneB && i <= TB) {
-              const int v = (int)((pickB >> 16) & 0x7FFFu) - (int)bias - gap + baseB;
-              if (MODE == SA_SEMIGLOBAL && v > bestB) {
-                bestB = v;
-                biB = i;
-              }
-              if (MODE == SA_GLOBAL && i == TB) finalB = v;
-            }
-          }
+          mx[k] = pk_max_u16(dc[k], Hg[k]);
+          if (MODE == SA_LOCAL) mx[k] = pk_max_u16(mx[k], floor2);
         }
-        // lane 63 finished row st - 63 of the strip's last column: collect NB of them, store coalesced
-        if (!last_strip && (FULL || st >= 64)) {
-          const uint32_t v63 = (uint32_t)__builtin_amdgcn_readlane((int)lastcol, 63);
-          const uint32_t row = st - 63;  // 1 ..
-          const uint32_t slot = (row - 1) & 63;
-          bout = lane == slot ? v63 : bout;
-          if ((slot & (NB - 1)) == NB - 1 || row == T) {
-            const uint32_t first_slot = slot & ~(NB - 1);  // rows of this hand-over: slots first_slot .. slot
-            const uint32_t base = row - slot;              // row held by slot 0
-            if (lane >= first_slot && lane <= slot) {
-              uint64_t e = (uint64_t)bout;
-              if (REL)  // absolute again: lane 63's bases
-                e = wave_pk_entry(s + 1, (int)(bout & 0x7FFFu) - (int)bias + b63A,
-                                  (int)((bout >> 16) & 0x7FFFu) - (int)bias + b63B);
-              __hip_atomic_store(&bcol[base + lane], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // pass 2: the dependent chain along the row (max with the left candidate, then + gap), with the
+        // flag work of the cell before interleaved so that the chain's latencies are covered.  Flags:
+        // candidate - max is negative (bit 15 of the half set) exactly when the candidate is NOT the
+        // maximum; one v_perm turns the four sign bits into four 0x00/0xFF bytes.
+        uint32_t left = recv, acc0 = 0, acc1 = 0, rowkey = 0;
+        auto flags = [&](int k, uint32_t lin) __attribute__((always_inline)) {
+          if (MODE == SA_LOCAL) rowkey = pk_max_u16(rowkey, mx[k] | rep2((uint32_t)(15 - k)));
+          const uint32_t signs =
+              __builtin_amdgcn_perm(pk_sub_u16(dc[k], mx[k]), pk_sub_u16(lin, mx[k]), 0x0B0A0908u);
+          if (k < 8)
+            acc0 = and_or(signs, 0x01010101u << (k & 7), acc0);
+          else
+            acc1 = and_or(signs, 0x01010101u << (k & 7), acc1);
+        };
+        uint32_t lin_prev = recv;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const uint32_t lin = left;
+          mx[k] = pk_max_u16(mx[k], left);
+          left = mx[k] - gsub2;  // S(H[i][column] + gap)
+          Hg[k] = left;
+          if (k > 0) flags(k - 1, lin_prev);
+          lin_prev = lin;
+        }
+        flags(C - 1, lin_prev);
+        // written once, read once by the traceback: keep it out of the caches
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(u32x2{acc0, acc1}, reinterpret_cast<u32x2*>(dst));
+        ldiag = recv;
+        lastcol = left;
+        if (MODE == SA_LOCAL) {
+          // a row replaces the strip's candidate only with a strictly larger score: with the low bits of
+          // the old key filled, an equal score never exceeds it
+          const uint32_t old = skey | 0x000F000Fu;
+          const uint32_t now = pk_max_u16(old, rowkey);
+          const uint32_t changed = now ^ old;
+          const bool upA = (changed & 0xFFFFu) != 0, upB = (changed >> 16) != 0;
+          skey = (upA ? now & 0x0000FFFFu : skey & 0x0000FFFFu) | (upB ? now & 0xFFFF0000u : skey & 0xFFFF0000u);
+          siA = upA ? i : siA;
+          siB = upB ? i : siB;
+        }
+        // a pair's last column is in this strip; Global wants it on one step only, the pair's last row
+        if (MODE != SA_LOCAL && PICK && (s == stripA || s == stripB) &&
+            (MODE != SA_GLOBAL || (s == stripA && st == TA + laneA) || (s == stripB && st == TB + laneB))) {
+          uint32_t pick = 0;  // low half: pair A's column regA, high half: pair B's column regB
+#pragma unroll
+          for (int k = 0; k < C; ++k) pick = and_or(Hg[k], pick_mask[k], pick);
+          const uint32_t pickA = pick, pickB = pick;
+          if (s == stripA && lane == laneA && i <= TA) {
+            const int v = (int)(pickA & 0x7FFFu) - (int)bias - gap + baseA;
+            if (MODE == SA_SEMIGLOBAL && v > bestA) {  // src/alignment.cpp:87-92, rows in increasing order
+              bestA = v;
+              biA = i;
             }
+            if (MODE == SA_GLOBAL && i == TA) finalA = v;
+          }
+          if (s == stripB && lane == laneB && i <= TB) {
+            const int v = (int)((pickB >> 16) & 0x7FFFu) - (int)bias - gap + baseB;
+            if (MODE == SA_SEMIGLOBAL && v > bestB) {
+              bestB = v;
+              biB = i;
+            }
+            if (MODE == SA_GLOBAL && i == TB) finalB = v;
           }
         }
       };
-      for (uint32_t b0 = 1; b0 <= steps; b0 += NB) {  // batches of NB steps
-        if (lane < NB) {
-          const uint32_t pos = b0 + lane;  // target positions b0 .. b0 + NB - 1
-          tring[pos & 255u] = tsym(pos);
+      // Lane 63 finishes row st - 63 of the strip's last column in step st.  Sixteen of them are collected in lanes
+      // 0 .. 15 of `bout` (row - 1) % 16 and go to the next strip together: lanes 0 .. last hold rows base ..
+      auto hand_over = [&](uint32_t last, uint32_t base) __attribute__((always_inline)) {
+        if (lane <= last) {
+          uint64_t e = (uint64_t)bout;
+          if (REL)  // absolute again: lane 63's bases
+            e = wave_pk_entry(s + 1, (int)(bout & 0x7FFFu) - (int)bias + b63A,
+                              (int)((bout >> 16) & 0x7FFFu) - (int)bias + b63B);
+          __hip_atomic_store(&bcol[base + lane], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        uint64_t entry = 0;
+      };
+      // One step anywhere in the sweep: lanes whose row lies outside the matrix sit it out.
+      auto step = [&](uint32_t b0, uint32_t st) __attribute__((always_inline)) {
+        const uint2 tc = tring[(st - lane - 1) & 255u];  // (lanes that have not started read some other row)
+        uint32_t from_left = (uint32_t)dpp_from_lane_below((int)lastcol);
+        if (REL) from_left = pk_add_u16(from_left, adj2);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)bnext, st - b0);
+        const uint32_t recv = lane == 0 ? first : from_left;
+        const uint32_t i = st - lane;  // row of this lane in this step (valid when 1 <= i <= T)
+        if (st > lane && i <= T) cells(tc, recv, i, st, drow + (uint64_t)st * 64, std::true_type{});
+        if (!last_strip && st >= 64) {
+          const uint32_t v63 = (uint32_t)__builtin_amdgcn_readlane((int)lastcol, 63);
+          const uint32_t row = st - 63;  // 1 ..
+          const uint32_t slot = (row - 1) & 15u;
+          bout = lane == slot ? v63 : bout;
+          if (slot == 15u || row == T) hand_over(slot, row - slot);
+        }
+      };
+      // Sixteen steps from step g0 (g0 % 16 == 1, g0 >= 64, g0 + 15 <= T: every lane has a row in each of them), of
+      // batch b0: nothing is predicated, and everything that depends on the step's number within the group is a
+      // constant - the ring offset of the row's symbols, the lane of `bnext`, the slot of lane 63's value.
+      auto steps16 = [&](uint32_t b0, uint32_t g0) __attribute__((always_inline)) {
+        const uint2* tp = tring + ((g0 - lane - 1) & 255u);
+        uint2* dst = drow + (uint64_t)g0 * 64;
+        const uint32_t j0 = g0 - b0;
+        static_for<16>([&](auto xt) __attribute__((always_inline)) {
+          constexpr uint32_t X = decltype(xt)::value;
+          const uint2 tc = tp[X];
+          const int first = __builtin_amdgcn_readlane((int)bnext, j0 + X);
+          // lane 0 takes the boundary value, every other lane the value of the lane below
+          uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(first, (int)lastcol, 0x138, 0xF, 0xF, false);
+          if (REL) recv = pk_add_u16(recv, adj2);  // (lane 0's adjustment is zero)
+          cells(tc, recv, g0 + X - lane, g0 + X, dst + (uint64_t)X * 64, std::integral_constant<bool, MODE != SA_GLOBAL>{});
+          if (!last_strip) {  // row g0 + X - 63 of the last column: slot (g0 + X - 64) % 16 = (X + 1) % 16
+            const int v63 = __builtin_amdgcn_readlane((int)lastcol, 63);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(bout) : "s"(v63), "n"((X + 1) & 15u));
+            if (X == 14) hand_over(15u, g0 - 64);
+          }
+        });
+      };
+      for (uint32_t b0 = 1; b0 <= steps; b0 += NB) {  // batches of NB steps
+        if (lane < NB) ring_put(b0 + lane, tconv(t_pre));  // target positions b0 .. b0 + NB - 1
+        uint64_t entry = e_pre;
+        if (b0 + NB <= steps) {
+          t_pre = lane < NB ? traw(b0 + NB + lane) : 0u;
+          e_pre = load_entries(b0 + NB);
+        }
         if (s > 0) {  // rows b0 .. b0 + NB - 1 of the previous strip's last column
-          const uint32_t row = b0 + lane;
-          const bool want = lane < NB && row <= T;
-          entry = want ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
           if (COOP) {  // (bounded) until all of them carry this strip's tag
+            const bool want = lane < NB && b0 + lane <= T;
             for (uint32_t polls = 0; !__all(!want || (uint32_t)(entry >> 48) == s); ++polls) {
               __builtin_amdgcn_s_sleep(1);
               if (polls >= co.spin_limit ||
@@ -361,10 +399,12 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
                 __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
               }
-              entry = want ? __hip_atomic_load(&bin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+              entry = load_entries(b0);
             }
           }
           if (!REL) bnext = (uint32_t)entry;
+        } else if (!REL) {
+          bnext = SG(border_col0<MODE>((int)(b0 + lane), gap) + gap);
         }
         if (REL) {
           if ((b0 & 63u) == 1u) {
@@ -381,8 +421,10 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
             bout = pk_sub_u16(bout, (uint32_t)__builtin_amdgcn_readlane((int)d2, 63));
             b63A = __builtin_amdgcn_readlane(baseA, 63);
             b63B = __builtin_amdgcn_readlane(baseB, 63);
-            adj2 = ((uint32_t)(dpp_from_lane_below(baseA) - baseA) & 0xFFFFu) |
-                   ((uint32_t)(dpp_from_lane_below(baseB) - baseB) << 16);
+            // (the lane shifts run with every lane enabled: a disabled lane's value cannot be read)
+            const int belowA = dpp_from_lane_below(baseA), belowB = dpp_from_lane_below(baseB);
+            const uint32_t adj = ((uint32_t)(belowA - baseA) & 0xFFFFu) | ((uint32_t)(belowB - baseB) << 16);
+            adj2 = lane == 0 ? 0u : adj;
           }
           // lane 0's left values of the batch, relative to lane 0's bases
           const int b0A = __builtin_amdgcn_readfirstlane(baseA), b0B = __builtin_amdgcn_readfirstlane(baseB);
@@ -390,12 +432,20 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
           bnext = s == 0 ? S2(left0 - b0A, left0 - b0B)
                          : S2(wave_pk_entry_a(entry) - b0A, wave_pk_entry_b(entry) - b0B);
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, so that no step has to wait on it
         if (b0 >= 64 && b0 + NB - 1 <= T) {
-          for (uint32_t x = 0; x < NB; ++x) step(b0 + x, std::true_type{});
+#pragma nounroll
+          for (uint32_t g0 = b0; g0 < b0 + NB; g0 += 16) {
+            // (Global: the group with the step in which a pair's last cell is computed takes the general steps)
+            const uint32_t pickA = TA + laneA - g0, pickB = TB + laneB - g0;
+            if (MODE == SA_GLOBAL && ((s == stripA && pickA < 16u) || (s == stripB && pickB < 16u))) {
+              for (uint32_t st = g0; st < g0 + 16; ++st) step(b0, st);
+            } else {
+              steps16(b0, g0);
+            }
+          }
         } else {
           const uint32_t e = b0 + NB - 1 < steps ? b0 + NB - 1 : steps;
-          for (uint32_t st = b0; st <= e; ++st) step(st, std::false_type{});
+          for (uint32_t st = b0; st <= e; ++st) step(b0, st);
         }
       }
       if (MODE == SA_LOCAL) {  // the strip's candidates against the lane's: higher score, then smaller row
