@@ -363,13 +363,41 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
       // Sixteen steps from step g0 (g0 % 16 == 1, g0 >= 64, g0 + 15 <= T: every lane has a row in each of them), of
       // batch b0: nothing is predicated, and everything that depends on the step's number within the group is a
       // constant - the ring offset of the row's symbols, the lane of `bnext`, the slot of lane 63's value.
-      auto steps16 = [&](uint32_t b0, uint32_t g0) __attribute__((always_inline)) {
+      // fetch_tag: the group also fetches the inputs of the batch after b0 - the loads leave in its first step and
+      // are waited for after its last, with the group's sixteen stores behind them in the queue: waiting for
+      // them at the start of the next batch would wait for those stores as well (a microsecond per batch).
+      auto steps16 = [&](uint32_t b0, uint32_t g0, auto fetch_tag) __attribute__((always_inline)) {
+        constexpr bool FETCH = decltype(fetch_tag)::value;
         const uint2* tp = tring + ((g0 - lane - 1) & 255u);
         uint2* dst = drow + (uint64_t)g0 * 64;
         const uint32_t j0 = g0 - b0;
+        // the rows' symbols leave LDS four steps before they are needed
+        // (without tables only the first word is in use: a loaded second word would be a dead register, handed out
+        // again at once and waited for then)
+        uint32_t tcx[16], tcy[16];
+        auto ring_get = [&](auto yt) __attribute__((always_inline)) {
+          constexpr uint32_t Y = decltype(yt)::value;
+          if (TAB) {
+            const uint2 v = tp[Y];
+            tcx[Y] = v.x;
+            tcy[Y] = v.y;
+          } else {
+            tcx[Y] = tp[Y].x;
+            tcy[Y] = 0;
+          }
+        };
+        static_for<4>(ring_get);
         static_for<16>([&](auto xt) __attribute__((always_inline)) {
           constexpr uint32_t X = decltype(xt)::value;
-          const uint2 tc = tp[X];
+          if (FETCH && X == 0) {
+            t_pre = lane < NB ? traw(b0 + NB + lane) : 0u;
+            e_pre = load_entries(b0 + NB);
+          }
+          if (X % 4 == 0 && X + 4 < 16)
+            static_for<4>([&](auto yt) __attribute__((always_inline)) {
+              ring_get(std::integral_constant<uint32_t, X + 4 + decltype(yt)::value>{});
+            });
+          const uint2 tc = make_uint2(tcx[X], tcy[X]);
           const int first = __builtin_amdgcn_readlane((int)bnext, j0 + X);
           // lane 0 takes the boundary value, every other lane the value of the lane below
           uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(first, (int)lastcol, 0x138, 0xF, 0xF, false);
@@ -380,12 +408,14 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
             asm("v_writelane_b32 %0, %1, %2" : "+v"(bout) : "s"(v63), "n"((X + 1) & 15u));
             if (X == 14) hand_over(15u, g0 - 64);
           }
+          if (FETCH && X == 15) asm volatile("" ::"v"(t_pre), "v"(e_pre));  // (the wait for the loads comes here)
         });
       };
       for (uint32_t b0 = 1; b0 <= steps; b0 += NB) {  // batches of NB steps
         if (lane < NB) ring_put(b0 + lane, tconv(t_pre));  // target positions b0 .. b0 + NB - 1
         uint64_t entry = e_pre;
-        if (b0 + NB <= steps) {
+        const bool full = b0 >= 64 && b0 + NB - 1 <= T;  // every lane has a row in every step of the batch
+        if (!full && b0 + NB <= steps) {
           t_pre = lane < NB ? traw(b0 + NB + lane) : 0u;
           e_pre = load_entries(b0 + NB);
         }
@@ -432,17 +462,23 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
           bnext = s == 0 ? S2(left0 - b0A, left0 - b0B)
                          : S2(wave_pk_entry_a(entry) - b0A, wave_pk_entry_b(entry) - b0B);
         }
-        if (b0 >= 64 && b0 + NB - 1 <= T) {
-#pragma nounroll
-          for (uint32_t g0 = b0; g0 < b0 + NB; g0 += 16) {
-            // (Global: the group with the step in which a pair's last cell is computed takes the general steps)
+        if (full) {
+          // (Global: the group with the step in which a pair's last cell is computed takes the general steps)
+          auto group = [&](uint32_t g0, auto fetch_tag) __attribute__((always_inline)) {
             const uint32_t pickA = TA + laneA - g0, pickB = TB + laneB - g0;
             if (MODE == SA_GLOBAL && ((s == stripA && pickA < 16u) || (s == stripB && pickB < 16u))) {
+              if (decltype(fetch_tag)::value) {
+                t_pre = lane < NB ? traw(b0 + NB + lane) : 0u;
+                e_pre = load_entries(b0 + NB);
+              }
               for (uint32_t st = g0; st < g0 + 16; ++st) step(b0, st);
             } else {
-              steps16(b0, g0);
+              steps16(b0, g0, fetch_tag);
             }
-          }
+          };
+          group(b0, std::true_type{});
+#pragma nounroll
+          for (uint32_t g0 = b0 + 16; g0 < b0 + NB; g0 += 16) group(g0, std::false_type{});
         } else {
           const uint32_t e = b0 + NB - 1 < steps ? b0 + NB - 1 : steps;
           for (uint32_t st = b0; st <= e; ++st) step(b0, st);
