@@ -46,6 +46,7 @@ Options& options() {
     x->coop_c = num("SA_COOP_C", 0);
     x->coop_waves = num("SA_COOP_WAVES", 8192);
     x->coop_pk = num("SA_COOP_PK", -1);
+    x->no_overlap = num("SA_NO_OVERLAP", 0);
     x->pk16_k = num("SA_PK16_K", 48);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
@@ -387,6 +388,79 @@ __global__ void clear_words(uint32_t* p, uint32_t n) {
   if (i < n) p[i] = 0;
 }
 
+// A second stream for a call: the traceback of the pairs whose fill has finished runs there while the last,
+// partly filled round of the fill's wavefronts runs on the caller's stream.  The objects are kept per device
+// and lent to one call at a time (batch calls may run on several host threads at once).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr;
+};
+std::mutex g_side_mutex;
+std::vector<SideStream> g_side_free[64];
+
+struct SideLease {
+  int device;
+  SideStream s;
+  bool ok = false;
+  explicit SideLease(int dev) : device(dev) {
+    if (dev < 0 || dev >= 64) return;
+    {
+      std::lock_guard<std::mutex> g(g_side_mutex);
+      if (!g_side_free[dev].empty()) {
+        s = g_side_free[dev].back();
+        g_side_free[dev].pop_back();
+        ok = true;
+        return;
+      }
+    }
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return;
+    if (hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.joined, hipEventDisableTiming) != hipSuccess)
+      return;
+    ok = true;
+  }
+  ~SideLease() {
+    if (!ok) return;
+    std::lock_guard<std::mutex> g(g_side_mutex);
+    g_side_free[device].push_back(s);
+  }
+};
+
+// Wavefronts of a fill launch come and go in rounds (they all take the same time): `resident` run at once, and a
+// launch of 2.5 rounds leaves half the GPU idle for the length of a round.  Units (wavefronts) of the launch's
+// whole rounds, when the rest is a partial round worth filling with other work; 0: do not split.
+uint32_t whole_rounds(uint32_t units, uint32_t resident) {
+  if (!resident || units < resident + resident / 8) return 0;
+  const uint32_t head = units / resident * resident, tail = units - head;
+  if (tail < resident / 10 || tail > resident - resident / 10) return 0;
+  return head;
+}
+
+int device_cus(int device) {
+  static int cus[64] = {};
+  if (device < 0 || device >= 64) return 256;
+  if (!cus[device]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+    cus[device] = v;
+  }
+  return cus[device];
+}
+
+// The arguments of the part of a pass that starts at its unit u0 and holds `pairs` pairs.
+AlignArgs sub_pass(const Plan& pl, const AlignArgs& a, uint32_t u0, uint32_t pairs) {
+  AlignArgs x = a;
+  const uint32_t p0 = u0 * pl.pairs_per_unit;
+  x.pair_base = a.pair_base + p0;
+  x.pairs_in_pass = pairs;
+  x.dirs = a.dirs + (uint64_t)u0 * pl.dirs_unit_stride;
+  x.brow = a.brow + (uint64_t)u0 * pl.brow_unit_stride;
+  x.end_score = a.end_score + p0;
+  x.end_i = a.end_i + p0;
+  x.end_r = a.end_r + p0;
+  return x;
+}
+
 template <int MODE>
 int launch_lane_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback) {
   const uint32_t blocks = (a.pairs_in_pass + kBlock - 1) / kBlock;
@@ -409,23 +483,15 @@ int launch_lane_i32(const AlignArgs& a, hipStream_t stream, bool need_traceback)
 
 template <int MODE, int K>
 int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t* tpk,
-                     AlphabetInfo* alpha, hipStream_t stream, bool need_traceback) {
+                     AlphabetInfo* alpha, hipStream_t stream, bool need_traceback, int overlap_device) {
   const uint32_t units = (a.pairs_in_pass + 127) / 128;
   // Tables form: the traceback reads the pairs' symbols from per-pair records of 2-bit codes.  They live in the
   // three quarters of every unit's target area that the one-byte-per-position form leaves unused, when they fit.
   const uint32_t q_tiles = (a.max_q + kPackTile - 1) / kPackTile, t_tiles = (pl.t_pad + kPackTile - 1) / kPackTile;
-  AlignArgs ar = a;
-  ar.rec = nullptr;
-  uint32_t* rec = nullptr;
   const uint64_t rec_unit_dwords = 128ull * 4 * (q_tiles + t_tiles);
-  if (alpha && need_traceback && pl.t_pad % 4 == 0 && (uint64_t)pl.t_pad / 4 * 64 + rec_unit_dwords <= pl.tpk_unit_words) {
-    rec = tpk + (uint64_t)pl.t_pad / 4 * 64;
-    ar.rec = rec;
-    ar.rec_unit_stride = pl.tpk_unit_words;
-    ar.rec_stride = 4 * (q_tiles + t_tiles);
-    ar.rec_q_chunks = q_tiles;
-    ar.rec_alpha = alpha;
-  }
+  const bool with_rec = alpha && need_traceback && pl.t_pad % 4 == 0 &&
+                        (uint64_t)pl.t_pad / 4 * 64 + rec_unit_dwords <= pl.tpk_unit_words;
+  uint32_t* rec = with_rec ? tpk + (uint64_t)pl.t_pad / 4 * 64 : nullptr;
   {
     Timed tm(stream, 0);
     PackArgs pk{a.q, a.q_off, a.t, a.t_off, a.pair_base, a.pairs_in_pass, a.max_q, pl.t_pad,
@@ -438,23 +504,61 @@ int launch_lane_pk16(const Plan& pl, const AlignArgs& a, uint32_t* qpk, uint32_t
     }
   }
   SA_HIP_TRY(hipGetLastError());
-  Pk16Args x{qpk, tpk, pl.t_pad, pl.bias, units, alpha, pl.entry_match, pl.entry_mismatch};
-  {
-    Timed tm(stream, 1);
+  // the fill and the traceback of the units [u0, u0 + nu) of the pass
+  auto fill = [&](uint32_t u0, uint32_t nu, hipStream_t st) {
+    const AlignArgs x = sub_pass(pl, a, u0, std::min<uint32_t>(nu * 128, a.pairs_in_pass - u0 * 128));
+    Pk16Args y{qpk + (uint64_t)u0 * pl.qpk_unit_words, tpk + (uint64_t)u0 * pl.tpk_unit_words, pl.t_pad, pl.bias, nu,
+               alpha, pl.entry_match, pl.entry_mismatch};
+    Timed tm(st, 1);
     if (alpha)
-      hipLaunchKernelGGL((fill_lane_pk16<MODE, K, true>), dim3((units + 3) / 4), dim3(kBlock), 0, stream,
-                         a, x);
+      hipLaunchKernelGGL((fill_lane_pk16<MODE, K, true>), dim3((nu + 3) / 4), dim3(kBlock), 0, st, x, y);
     else
-      hipLaunchKernelGGL((fill_lane_pk16<MODE, K, false>), dim3((units + 3) / 4), dim3(kBlock), 0,
-                         stream, a, x);
+      hipLaunchKernelGGL((fill_lane_pk16<MODE, K, false>), dim3((nu + 3) / 4), dim3(kBlock), 0, st, x, y);
+  };
+  auto traceback = [&](uint32_t u0, uint32_t nu, hipStream_t st) {
+    AlignArgs x = sub_pass(pl, a, u0, std::min<uint32_t>(nu * 128, a.pairs_in_pass - u0 * 128));
+    x.rec = nullptr;
+    if (with_rec) {
+      x.rec = rec + (uint64_t)u0 * pl.tpk_unit_words;
+      x.rec_unit_stride = pl.tpk_unit_words;
+      x.rec_stride = 4 * (q_tiles + t_tiles);
+      x.rec_q_chunks = q_tiles;
+      x.rec_alpha = alpha;
+    }
+    Timed tm(st, 2);
+    hipLaunchKernelGGL((traceback_lane_pk16<MODE, K>), dim3((x.pairs_in_pass + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x);
+  };
+  // units of the fill's whole rounds (blocks of four wavefronts, as many per CU as their registers allow)
+  uint32_t head = 0;
+  if (need_traceback && overlap_device >= 0) {
+    static int per_cu = 0;  // (the same for every instance of the template on this machine's GPUs)
+    if (!per_cu) {
+      int v = 0;
+      const hipError_t e = alpha ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fill_lane_pk16<MODE, K, true>, kBlock, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fill_lane_pk16<MODE, K, false>, kBlock, 0);
+      per_cu = (e == hipSuccess && v > 0) ? v : -1;
+    }
+    if (per_cu > 0) head = whole_rounds(units, (uint32_t)per_cu * device_cus(overlap_device) * 4);
   }
+  if (head) {
+    SideLease side(overlap_device);
+    if (side.ok) {
+      fill(0, head, stream);
+      SA_HIP_TRY(hipEventRecord(side.s.forked, stream));
+      SA_HIP_TRY(hipStreamWaitEvent(side.s.stream, side.s.forked, 0));
+      traceback(0, head, side.s.stream);
+      SA_HIP_TRY(hipEventRecord(side.s.joined, side.s.stream));
+      fill(head, units - head, stream);
+      traceback(head, units - head, stream);
+      SA_HIP_TRY(hipStreamWaitEvent(stream, side.s.joined, 0));
+      SA_HIP_TRY(hipGetLastError());
+      return SA_OK;
+    }
+  }
+  fill(0, units, stream);
   SA_HIP_TRY(hipGetLastError());
   if (need_traceback) {
-    {
-      Timed tm(stream, 2);
-      hipLaunchKernelGGL((traceback_lane_pk16<MODE, K>), dim3((a.pairs_in_pass + kBlock - 1) / kBlock),
-                         dim3(kBlock), 0, stream, ar);
-    }
+    traceback(0, units, stream);
     SA_HIP_TRY(hipGetLastError());
   }
   return SA_OK;
@@ -563,26 +667,60 @@ int launch_wave_coop2(const AlignArgs& a, const WaveCoop& co, hipStream_t stream
 }
 
 template <int MODE, int C, bool COOP>
-int launch_wave_pk16(const Plan& pl, const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback) {
+int launch_wave_pk16(const Plan& pl, const AlignArgs& a, const WaveCoop& co, hipStream_t stream, bool need_traceback,
+                     int overlap_device) {
   if constexpr (COOP && MODE == SA_LOCAL) {
     return fail(SA_ERR_ARGUMENT, "packed cooperative kernel chosen for Local");
   } else {
     const uint32_t units = (a.pairs_in_pass + 1) / 2;
-    {
+    // score tables inside the kernel (a wavefront whose sequences hold at most four distinct bytes): the
+    // entries (mismatch - gap) and (match - mismatch) << SH must be non-negative bytes
+    const int sh = MODE == SA_LOCAL ? 4 : 0;
+    const uint32_t tables = !options().no_tables && a.mismatch - a.gap >= 0 &&
+                            ((long)(a.mismatch - a.gap) << sh) <= 255 && ((long)(a.match - a.mismatch) << sh) <= 255;
+    auto fill = [&](const AlignArgs& x, uint32_t blocks) {
       Timed tm(stream, 1);
-      // score tables inside the kernel (a wavefront whose sequences hold at most four distinct bytes): the
-      // entries (mismatch - gap) and (match - mismatch) << SH must be non-negative bytes
-      const int sh = MODE == SA_LOCAL ? 4 : 0;
-      const uint32_t tables = !options().no_tables && a.mismatch - a.gap >= 0 &&
-                              ((long)(a.mismatch - a.gap) << sh) <= 255 && ((long)(a.match - a.mismatch) << sh) <= 255;
-      if (COOP) {
-        SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
-        // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
-        SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)units * a.brow_unit_stride * 4, stream));
+      hipLaunchKernelGGL((fill_wave_pk16<MODE, C, COOP>), dim3(blocks), dim3(64), 0, stream, x, co, pl.bias, tables);
+    };
+    // One wavefront per two pairs: the traceback of the pairs of the fill's whole rounds runs on a second
+    // stream under the last, partly filled round.
+    uint32_t head = 0;
+    if (!COOP && need_traceback && overlap_device >= 0) {
+      static int per_cu = 0;
+      if (!per_cu) {
+        int v = 0;
+        per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fill_wave_pk16<MODE, C, COOP>, 64, 0) == hipSuccess && v > 0) ? v : -1;
       }
-      hipLaunchKernelGGL((fill_wave_pk16<MODE, C, COOP>), dim3(COOP ? units * a.nstrips : units), dim3(64), 0, stream,
-                         a, co, pl.bias, tables);
+      if (per_cu > 0) head = whole_rounds(units, (uint32_t)per_cu * device_cus(overlap_device));
     }
+    if (head) {
+      SideLease side(overlap_device);
+      if (side.ok) {
+        const AlignArgs xa = sub_pass(pl, a, 0, head * 2), xb = sub_pass(pl, a, head, a.pairs_in_pass - head * 2);
+        fill(xa, head);
+        SA_HIP_TRY(hipEventRecord(side.s.forked, stream));
+        SA_HIP_TRY(hipStreamWaitEvent(side.s.stream, side.s.forked, 0));
+        {
+          Timed tm(side.s.stream, 2);
+          hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16<C>>), dim3(xa.pairs_in_pass), dim3(64), 0, side.s.stream, xa);
+        }
+        SA_HIP_TRY(hipEventRecord(side.s.joined, side.s.stream));
+        fill(xb, units - head);
+        {
+          Timed tm(stream, 2);
+          hipLaunchKernelGGL((traceback_wave<MODE, WaveFmtPk16<C>>), dim3(xb.pairs_in_pass), dim3(64), 0, stream, xb);
+        }
+        SA_HIP_TRY(hipStreamWaitEvent(stream, side.s.joined, 0));
+        SA_HIP_TRY(hipGetLastError());
+        return SA_OK;
+      }
+    }
+    if (COOP) {
+      SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
+      // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
+      SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)units * a.brow_unit_stride * 4, stream));
+    }
+    fill(a, COOP ? units * a.nstrips : units);
     SA_HIP_TRY(hipGetLastError());
     if (need_traceback) {
       if constexpr (COOP) {
@@ -599,14 +737,14 @@ int launch_wave_pk16(const Plan& pl, const AlignArgs& a, const WaveCoop& co, hip
 
 template <int MODE>
 int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t* qpk, uint32_t* tpk,
-                AlphabetInfo* alpha, hipStream_t stream, bool need_tb) {
+                AlphabetInfo* alpha, hipStream_t stream, bool need_tb, int overlap_device) {
   if (pl.family == Family::LaneI32) return launch_lane_i32<MODE>(a, stream, need_tb);
   if (pl.family == Family::WaveI32 && pl.wave_pk && pl.coop)
-    return pl.wave_c == 8    ? launch_wave_pk16<MODE, 8, true>(pl, a, co, stream, need_tb)
-           : pl.wave_c == 10 ? launch_wave_pk16<MODE, 10, true>(pl, a, co, stream, need_tb)
-           : pl.wave_c == 12 ? launch_wave_pk16<MODE, 12, true>(pl, a, co, stream, need_tb)
-                             : launch_wave_pk16<MODE, 16, true>(pl, a, co, stream, need_tb);
-  if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE, 16, false>(pl, a, co, stream, need_tb);
+    return pl.wave_c == 8    ? launch_wave_pk16<MODE, 8, true>(pl, a, co, stream, need_tb, -1)
+           : pl.wave_c == 10 ? launch_wave_pk16<MODE, 10, true>(pl, a, co, stream, need_tb, -1)
+           : pl.wave_c == 12 ? launch_wave_pk16<MODE, 12, true>(pl, a, co, stream, need_tb, -1)
+                             : launch_wave_pk16<MODE, 16, true>(pl, a, co, stream, need_tb, -1);
+  if (pl.family == Family::WaveI32 && pl.wave_pk) return launch_wave_pk16<MODE, 16, false>(pl, a, co, stream, need_tb, overlap_device);
   if (pl.family == Family::WaveI32 && pl.coop && MODE != SA_LOCAL)
     return pl.wave_c == 2   ? launch_wave_coop2<MODE, 2>(a, co, stream, need_tb)
            : pl.wave_c == 4 ? launch_wave_coop2<MODE, 4>(a, co, stream, need_tb)
@@ -618,9 +756,9 @@ int launch_pass(const Plan& pl, const AlignArgs& a, const WaveCoop& co, uint32_t
            : pl.wave_c == 8 ? launch_wave_i32<MODE, 8, false>(a, co, stream, need_tb)
                             : launch_wave_i32<MODE, 16, false>(a, co, stream, need_tb);
   switch (pl.K) {
-    case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, alpha, stream, need_tb);
-    case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb);
-    default: return launch_lane_pk16<MODE, 48>(pl, a, qpk, tpk, alpha, stream, need_tb);
+    case 32: return launch_lane_pk16<MODE, 32>(pl, a, qpk, tpk, alpha, stream, need_tb, overlap_device);
+    case 64: return launch_lane_pk16<MODE, 64>(pl, a, qpk, tpk, alpha, stream, need_tb, overlap_device);
+    default: return launch_lane_pk16<MODE, 48>(pl, a, qpk, tpk, alpha, stream, need_tb, overlap_device);
   }
 }
 
@@ -647,7 +785,7 @@ int sa_set_option(const char* name, long value) {
     std::atomic<long>* slot;
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"coop_waves", &o.coop_waves},
-               {"coop_pk", &o.coop_pk},
+               {"coop_pk", &o.coop_pk},       {"no_overlap", &o.no_overlap},
                {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
@@ -963,16 +1101,18 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
   a.cigar_stride = b->cigar_stride;
 
   const bool need_tb = b->d_target_begin || b->d_cigar_runs || b->d_cigar_nruns;
+  // (the static-scratch call creates nothing, a second stream included; the option "no_overlap" is a test hook)
+  const int overlap_device = (static_scratch_call || options().no_overlap) ? -1 : device;
   for (size_t base = 0; base < b->n; base += pairs_per_pass) {
     a.pair_base = (uint32_t)base;
     a.pairs_in_pass = (uint32_t)((b->n - base) < pairs_per_pass ? (b->n - base) : pairs_per_pass);
     int rc;
     if (b->type == SA_GLOBAL)
-      rc = launch_pass<SA_GLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb);
+      rc = launch_pass<SA_GLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb, overlap_device);
     else if (b->type == SA_LOCAL)
-      rc = launch_pass<SA_LOCAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb);
+      rc = launch_pass<SA_LOCAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb, overlap_device);
     else
-      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb);
+      rc = launch_pass<SA_SEMIGLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb, overlap_device);
     if (rc) return rc;
   }
   if (pl.coop) {  // the cooperative kernels report a wait that ran out through a flag
