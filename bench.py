@@ -16,7 +16,8 @@ Prints ONE JSON line on rank 0.  Besides the headline it carries `legs`: the oth
 timed the same way with its own roofline object - Needleman-Wunsch 10 000 pairs of 1 kbp x 1 kbp,
 semi-global 10 kbp x 11 kbp (25 000 pairs per GPU, run in as many passes as the workspace needs; under
 --gpus N a fixed set of 200 000 pairs is split over the ranks instead: strong scaling), one global
-100 kbp x 100 kbp pair - and `minimizers` (MinimizeBinary k=15 w=5 on a 4.6 Mbp genome and on 1 Gbp of reads).
+100 kbp x 100 kbp pair, `host_queue`: one call of the host-buffer entry point over every GPU the process sees -
+and `minimizers` (MinimizeBinary k=15 w=5 on a 4.6 Mbp genome and on 1 Gbp of reads).
 """
 import argparse
 import ctypes as C
@@ -43,7 +44,7 @@ WORKLOADS = {
     "sw_150x300": (1, 1_000_000, 150, 300),
     "nw_1kx1k": (0, 10_000, 1000, 1000),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_per_launch.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_per_launch.json")
 
 
 def make_pairs(workload, n, seed):
@@ -104,16 +105,37 @@ def cpu_baseline(q, t, typ, sample, threads, note=""):
             "sample": f"{sample} pairs of the same workload{note}, CIGAR on, {dt:.1f} s"}, scores
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed counter passes (tools/profile_round.sh: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled for gfx950's half-counted coalesced reads).
-    Counters cannot be collected inside this process."""
+def pmc_entries(section, kernel_substr):
+    """The entries of the committed counter summary (tools/summarize_pmc.py) for a kernel: one per (kernel, number
+    of workgroups) met in the section's runs - "bench", "minimizers_reads", "minimizers_genome" are runs of
+    their own, so a launch on the genome is never averaged with one on the reads."""
     try:
         pmc = json.load(open(PMC_FILE))
-        k = next(v for name, v in pmc.items() if kernel_substr in name)
-        return (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except (OSError, StopIteration, KeyError, ValueError):
+        return [v for name, v in pmc.get(section, {}).items() if kernel_substr in name]
+    except (OSError, ValueError):
+        return []
+
+
+def pmc_commit():
+    try:
+        return json.load(open(PMC_FILE)).get("_meta", {}).get("commit")
+    except (OSError, ValueError):
         return None
+
+
+def pmc_traffic(section, kernel_substr, blocks=None):
+    """HBM bytes per launch of a kernel from the committed counter passes (tools/profile_round.sh: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled for gfx950's half-counted wide reads).  blocks: the
+    launch's number of workgroups (the entry with that grid; None: the mean over the kernel's launches).
+    Counters cannot be collected inside this process; the file names the commit it was collected at."""
+    es = pmc_entries(section, kernel_substr)
+    if blocks is not None:
+        es = [e for e in es if e.get("blocks") == blocks]
+    es = [e for e in es if "FETCH_SIZE" in e and "WRITE_SIZE" in e]
+    if not es:
+        return None
+    n = sum(e["dispatches"] for e in es)
+    return sum((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0 * e["dispatches"] for e in es) / n
 
 
 def timed_alignment(lib, batch, steps, warmup, world=None, sdist=None):
@@ -165,10 +187,12 @@ def roofline_of(batch, typ, cells_rank, steps, ms, cnt, pmc_key=None):
         "algorithmic_bytes": cells_per_launch / 4,
     }
     if pmc_key:
-        tr = pmc_traffic(pmc_key)
+        tr = pmc_traffic("bench", pmc_key)
         if tr is not None:
             r["traffic"] = tr
-            r["traffic_unit"] = "bytes per fill launch (%s)" % os.path.relpath(PMC_FILE, ROOT)
+            r["traffic_unit"] = ("bytes per fill launch, mean over the launches of a step (%s, collected at commit %s "
+                                 "with the option no_overlap, which keeps a step's fill in one launch)"
+                                 % (os.path.relpath(PMC_FILE, ROOT), pmc_commit()))
     return r
 
 
@@ -260,7 +284,7 @@ def leg_nw_1k(lib, dev, steps, warmup, threads, with_cpu):
     out = {"workload": f"nw_1kx1k: {n} pairs, query {ql} x target {tl}, Global, match 1 mismatch -1 gap -1, "
                        "full CIGAR + target_begin",
            "value": b.cells * steps / elapsed / 1e9, "unit": "GCUPS", "ms_per_step": elapsed / steps * 1e3,
-           "steps": steps, "roofline": roofline_of(b, typ, float(b.cells), steps, ms, cnt, "fill_wave_pk16<0")}
+           "steps": steps, "roofline": roofline_of(b, typ, float(b.cells), steps, ms, cnt, "fill_wave_pk16<0, 16, false>")}
     if with_cpu:
         cpu, cpu_scores = cpu_baseline(q, t, typ, n, threads)
         cpu["scores_equal_gpu"] = bool(np.array_equal(cpu_scores, b.scores()))
@@ -293,7 +317,7 @@ def leg_sg_10k(lib, dev, steps, warmup, threads, with_cpu, n, first=0, world=Non
            "steps": steps, "passes_per_step": cnt[1] // steps,
            "workspace_GB": b.workspace_bytes / 1e9,
            "cigars_rescore_to_score": ok, "query_consumed_min_max": [qmin, qmax],
-           "roofline": roofline_of(b, typ, cells, steps, ms, cnt, "fill_wave_pk16<2")}
+           "roofline": roofline_of(b, typ, cells, steps, ms, cnt, "fill_wave_pk16<2, 16, false>")}
     if with_cpu:
         sample = min(n, max(threads, 16))
         q = q_dev[:sample].cpu().numpy()
@@ -380,14 +404,18 @@ def pcie_leg(lib, q, t, typ, pairs):
             "note": "sa_align_batch_host: pinned staging + H2D + kernels + D2H (+ one malloc'ed CIGAR string per pair)"}
 
 
-def minimizer_leg(dev, steps, cpu_threads, with_cpu):
+def minimizer_leg(dev, steps, cpu_threads, with_cpu, only=None):
     """Secondary metric of the same hot path: MinimizeBinary k=15 w=5 on a 4.6 Mbp genome (one sequence)
     and on 1 Gbp of 10 kbp reads (100 000 sequences), inputs resident in HBM.  Returns a dict."""
     import torch
     from sequencealigner_amd import minimize, synth
     out = {"k": 15, "w": 5}
-    for name, seqs in (("genome_4.6Mbp", [synth.genome(4_600_000, seed=4)]),
-                       ("reads_100k_x_10kbp", synth.reads(100_000, 10_000, seed=6))):
+    for name, make in (("genome_4.6Mbp", lambda: [synth.genome(4_600_000, seed=4)]),
+                       ("reads_100k_x_10kbp", lambda: synth.reads(100_000, 10_000, seed=6))):
+        if only and not name.startswith(only):
+            continue
+        seqs = make()
+        section = "minimizers_reads" if name.startswith("reads") else "minimizers_genome"
         b = minimize.DeviceMinimizeBatch(seqs, 15, 5, device=dev)
         b.run()
         torch.cuda.synchronize()
@@ -401,13 +429,27 @@ def minimizer_leg(dev, steps, cpu_threads, with_cpu):
         # the per-strand state machine is integer compare/select work: per window 3 ops to roll the k-mer,
         # per strand 4 for the step and 2 per re-scanned k-mer of an expiring minimum, 6 to pick and emit
         ops = 3 + 2 * (4 + 2 * 5) + 6
+        # HBM bytes of the leg's kernels from the counter passes over this leg alone
+        kernels = {}
+        for e_name in ("min_run<sa::Machine<5u, false>, 15u>", "sort_emit_small", "bucket_scatter", "bucket_plan"):
+            tr = pmc_traffic(section, e_name)
+            if tr is not None:
+                es = pmc_entries(section, e_name)
+                kernels[e_name.split("<")[0]] = {"traffic": tr, "fetch_bytes": 2048.0 * es[0]["FETCH_SIZE"],
+                                                 "write_bytes": 1024.0 * es[0]["WRITE_SIZE"],
+                                                 "valu_wave_instructions": es[0].get("SQ_INSTS_VALU")}
+        traffic = sum(k["traffic"] for k in kernels.values()) if kernels else None
         tops = b.windows / dt * ops / 1e12
         gbs = bytes_alg / dt / 1e9
         out[name] = {"ms": dt * 1e3, "windows_per_s": b.windows / dt, "minimizers_per_s": n_out / dt,
                      "unique_minimizers": n_out,
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": bytes_alg,
-                                  "traffic": pmc_traffic("min_run") if name.startswith("reads") else None,
+                                  "traffic": traffic, "traffic_by_kernel": kernels,
+                                  "traffic_unit": "bytes per call, summed over its kernels (%s, commit %s)"
+                                                  % (os.path.relpath(PMC_FILE, ROOT), pmc_commit()),
+                                  "fetch_over_bases": (kernels["min_run"]["fetch_bytes"] / b.total_len
+                                                       if "min_run" in kernels else None),
                                   "valu_int": {"achieved": tops, "peak": PEAK_I32_TOPS,
                                                "unit": "Tops/s (integer lane-ops; %d per window)" % ops,
                                                "frac": tops / PEAK_I32_TOPS}}}
@@ -436,6 +478,74 @@ def minimizer_leg(dev, steps, cpu_threads, with_cpu):
     return out
 
 
+def sg_split(total, world_size, rank):
+    """The semi-global leg under N > 1 ranks: one fixed set of `total` pairs of equal cost, dealt by cost like the
+    library's own shards (sequencealigner_amd.dist.shard_by_cost): equal costs give contiguous blocks.
+    -> (first pair of this rank, pairs of this rank)"""
+    from sequencealigner_amd import dist as sdist
+    shards = sdist.shard_by_cost(np.full(total, 10_000 * 11_000, dtype=np.int64), world_size)
+    mine = shards[rank]
+    return (int(mine[0]) if len(mine) else 0), len(mine)
+
+
+def host_queue_leg(lib, pairs_per_device):
+    """sa_align_batch_host - the library's own queue: one host thread, stream and set of buffers per GPU - over
+    every GPU this process sees, on semi-global 10 kbp x 11 kbp pairs (21 KB of input per 1.1e8 cells: the shape
+    on which a node's GPUs are not held back by the host's staging copies).  Wall time of the call, PCIe and
+    CIGAR text included, and the time every device's shard spent in its stages (the library's SA_HOST_TRACE
+    lines, read back from stderr)."""
+    import tempfile
+    import torch
+    from sequencealigner_amd import capi
+    ndev = int(lib.sa_device_count())
+    n = pairs_per_device * ndev
+    q_dev, t_dev = device_pairs_semiglobal(0, n, seed=11, dev=torch.device("cuda", torch.cuda.current_device()))
+    q, t = q_dev.cpu().numpy(), t_dev.cpu().numpy()
+    del q_dev, t_dev
+    qp = (C.c_char_p * n)(*[C.c_char_p(q.ctypes.data + i * q.shape[1]) for i in range(n)])
+    tp = (C.c_char_p * n)(*[C.c_char_p(t.ctypes.data + i * t.shape[1]) for i in range(n)])
+    ql = (C.c_uint32 * n)(*([q.shape[1]] * n))
+    tl = (C.c_uint32 * n)(*([t.shape[1]] * n))
+    scores, tb = (C.c_int32 * n)(), (C.c_uint32 * n)()
+
+    def call():
+        cig = (C.c_void_p * n)()
+        t0 = time.perf_counter()
+        capi.check(lib.sa_align_batch_host(qp, ql, tp, tl, n, 2, 1, -1, -1, 0, scores, tb, cig))
+        dt = time.perf_counter() - t0
+        for i in range(n):
+            lib.sa_free(cig[i])
+        return dt
+
+    call()                                   # warm: buffers, streams, code objects on every device
+    best = min(call() for _ in range(2))
+    # once more with the stage trace on (the library reads SA_HOST_TRACE at every shard), stderr into a file
+    per_device = {}
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        sys.stderr.flush()
+        saved = os.dup(2)
+        os.environ["SA_HOST_TRACE"] = "1"
+        try:
+            os.dup2(tmp.fileno(), 2)
+            traced = call()
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+            del os.environ["SA_HOST_TRACE"]
+        tmp.seek(0)
+        for line in tmp.read().decode(errors="replace").splitlines():
+            f = line.split()
+            if len(f) >= 6 and f[0] == "[sa" and f[1] == "host" and f[2] == "dev":
+                d = f[3].rstrip("]")
+                per_device[d] = per_device.get(d, 0.0) + float(f[-2])
+    cells = float(n) * q.shape[1] * t.shape[1]
+    return {"workload": f"host_queue: {n} pairs ({pairs_per_device} per GPU), query 10000 x target 11000, Semiglobal, "
+                        "host buffers in, CIGAR strings out, one call of sa_align_batch_host over all GPUs",
+            "devices": ndev, "value": cells / best / 1e9, "unit": "GCUPS (PCIe and CIGAR text included)",
+            "ms_per_call": best * 1e3, "ms_per_call_traced": traced * 1e3,
+            "device_busy_ms": per_device}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -448,13 +558,42 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-minimizers", action="store_true", help="skip the secondary minimizer metric")
     ap.add_argument("--no-legs", action="store_true", help="skip the other alignment shapes")
-    ap.add_argument("--legs", default="nw_1kx1k,sg_10kx11k,nw_100kx100k,pcie",
+    ap.add_argument("--legs", default="nw_1kx1k,sg_10kx11k,nw_100kx100k,pcie,host_queue",
                     help="comma-separated legs to run besides the headline")
     ap.add_argument("--leg-steps", type=int, default=0, help="timed steps of every leg (default: 5 / 2 / 3)")
     ap.add_argument("--sg-pairs", type=int, default=25_000, help="semi-global leg: pairs per GPU (one GPU)")
     ap.add_argument("--sg-total", type=int, default=200_000,
                     help="semi-global leg under --gpus N > 1: size of the fixed set that is split over the ranks")
+    ap.add_argument("--queue-pairs", type=int, default=1024, help="host_queue leg: pairs per GPU")
+    ap.add_argument("--only-minimizers", default="", help="run only this minimizer leg (reads | genome): counter passes")
+    ap.add_argument("--split-only", action="store_true",
+                    help="no GPU work: every rank computes its share of the semi-global set, rank 0 prints the line")
     args = ap.parse_args()
+
+    if args.split_only:   # the N-rank split logic, runnable on CPU ranks (gloo)
+        from sequencealigner_amd import dist as sdist
+        world = sdist.init()
+        first, count = sg_split(args.sg_total, world.size, world.rank)
+        total = sdist.reduce_sum(world, count)
+        last = sdist.reduce_max(world, first + count)
+        out = None
+        if world.rank == 0:
+            out = {"metric": "split only", "n_gpus": world.size,
+                   "legs": {"sg_10kx11k": {"scaling": "strong" if world.is_dist else "weak",
+                                           "pairs_this_rank": count, "first_pair_this_rank": first,
+                                           "pairs_all_ranks": int(total), "end_of_last_shard": int(last),
+                                           "sg_total": args.sg_total}}}
+            print(json.dumps(out), flush=True)
+        sdist.finalize(world)
+        return out
+    if args.only_minimizers:
+        import torch
+        from sequencealigner_amd import capi
+        torch.cuda.set_device(0)
+        capi.lib()
+        out = {"minimizers": minimizer_leg(0, 1, 1, False, only=args.only_minimizers)}
+        print(json.dumps(out), flush=True)
+        return out
 
     import torch
     from sequencealigner_amd import align, capi, dist as sdist
@@ -490,10 +629,10 @@ def main():
     # the semi-global leg under N > 1 GPUs: one fixed set, split over the ranks (strong scaling)
     sg_strong = None
     if world.is_dist and "sg_10kx11k" in legs_wanted:
-        shards = sdist.shard_by_cost(np.full(args.sg_total, 10_000 * 11_000, dtype=np.int64), world.size)
-        mine = shards[world.rank]          # equal costs: a contiguous block
-        sg_strong = leg_sg_10k(lib, dev, 1, 1, threads, False, len(mine), first=int(mine[0]), world=world,
+        first, count = sg_split(args.sg_total, world.size, world.rank)   # equal costs: a contiguous block
+        sg_strong = leg_sg_10k(lib, dev, 1, 1, threads, False, count, first=first, world=world,
                                sdist=sdist, total=args.sg_total)
+    sdist.barrier(world)   # every rank's GPU work is done: what follows on rank 0 has the node to itself
 
     out = None
     if world.rank == 0:
@@ -502,7 +641,14 @@ def main():
         if sample < 0:
             sample = min(n, 1_000_000 if args.workload == "sw_150x300" else 300)
         with_cpu = sample > 0 and not world.is_dist
-        if with_cpu:
+        if world.is_dist and sample > 0:
+            # N > 1: a bounded sample on rank 0's share of the host cores, after the timed region (the other
+            # ranks wait in the barrier at the end)
+            sample = min(sample, 20_000)
+            cpu, cpu_scores = cpu_baseline(q, t, typ, sample, threads,
+                                           f" (rank 0 of {world.size}, after the timed region)")
+            cpu["scores_equal_gpu"] = bool(np.array_equal(cpu_scores, gpu_scores[:sample]))
+        elif with_cpu:
             cpu, cpu_scores = cpu_baseline(q, t, typ, sample, threads)
             cpu["scores_equal_gpu"] = bool(np.array_equal(cpu_scores, gpu_scores[:sample]))
         out = {
@@ -520,19 +666,25 @@ def main():
         legs = {}
         if sg_strong is not None:
             legs["sg_10kx11k"] = sg_strong
-        if not world.is_dist:
-            if "pcie" in legs_wanted and args.workload == "sw_150x300" and not args.no_cigar:
-                out["pcie"] = pcie_leg(lib, q, t, typ, 200_000)
-            if "nw_1kx1k" in legs_wanted:
-                legs["nw_1kx1k"] = leg_nw_1k(lib, dev, args.leg_steps or 5, 2 if not args.leg_steps else 1, threads,
-                                             with_cpu)
-            if "sg_10kx11k" in legs_wanted:
-                legs["sg_10kx11k"] = leg_sg_10k(lib, dev, args.leg_steps or 2, 1, threads, with_cpu, args.sg_pairs)
-            if "nw_100kx100k" in legs_wanted:
-                legs["nw_100kx100k"] = leg_nw_100k(lib, dev, args.leg_steps or 3, 1, with_cpu)
+        # (under N > 1 ranks these run on rank 0's GPU after the timed region: per-GPU figures, labelled as such)
+        if "pcie" in legs_wanted and args.workload == "sw_150x300" and not args.no_cigar:
+            out["pcie"] = pcie_leg(lib, q, t, typ, 200_000)
+        if "nw_1kx1k" in legs_wanted:
+            legs["nw_1kx1k"] = leg_nw_1k(lib, dev, args.leg_steps or 5, 2 if not args.leg_steps else 1, threads,
+                                         with_cpu)
+        if "sg_10kx11k" in legs_wanted and not world.is_dist:
+            legs["sg_10kx11k"] = leg_sg_10k(lib, dev, args.leg_steps or 2, 1, threads, with_cpu, args.sg_pairs)
+        if "nw_100kx100k" in legs_wanted:
+            legs["nw_100kx100k"] = leg_nw_100k(lib, dev, args.leg_steps or 3, 1, with_cpu)
+        if world.is_dist:
+            for name in ("nw_1kx1k", "nw_100kx100k"):
+                if name in legs:
+                    legs[name]["n_gpus"] = 1
+        if "host_queue" in legs_wanted:   # one process, every visible GPU (the other ranks are idle by now)
+            legs["host_queue"] = host_queue_leg(lib, args.queue_pairs)
         if legs:
             out["legs"] = legs
-        if not args.no_minimizers and not world.is_dist:
+        if not args.no_minimizers:
             out["minimizers"] = minimizer_leg(dev, args.leg_steps or 3, threads, with_cpu)
         print(json.dumps(out), flush=True)
     sdist.finalize(world)

@@ -135,12 +135,15 @@ unsigned host_threads() {
 
 // SA_HOST_TRACE=1 prints the wall time of each stage of a shard to stderr.
 struct StageTimer {
+  int device;
   bool on = getenv("SA_HOST_TRACE") != nullptr;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit StageTimer(int dev) : device(dev) {}
   void mark(const char* what) {
     if (!on) return;
     const auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[sa host] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    fprintf(stderr, "[sa host dev %d] %-24s %8.3f ms\n", device, what,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
     t0 = t1;
   }
 };
@@ -219,7 +222,7 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   hipStream_t st = c.stream;
   enum { Q, T, QO, TO, SCORE, TB, NRUNS, RUNS, OFF, WS, COMPACT };
 
-  StageTimer trace;
+  StageTimer trace(device);
   // pinned staging: offsets first, then the sequences (8 bytes of slack: the kernels read aligned 8-byte words)
   int rc;
   if ((rc = c.pin[QO].ensure((n + 1) * 8)) || (rc = c.pin[TO].ensure((n + 1) * 8))) return rc;
@@ -359,7 +362,7 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   HostContext& c = *lease.c;
   hipStream_t st = c.stream;
   enum { SEQ, OFF, OUT, OOFF, STATUS, WS };
-  StageTimer trace;
+  StageTimer trace(device);
   int rc;
   if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
   uint64_t* ho = c.pin[OFF].as<uint64_t>();

@@ -62,3 +62,28 @@ def test_two_ranks_agree_on_split_and_reductions():
     assert res[0][2] == res[1][2] == float((qlen * tlen).sum())   # SUM over ranks
     assert res[0][3] == res[1][3] == 2.0                          # MAX over ranks
     assert res[0][4] != res[1][4]                                 # per-rank inputs differ
+
+
+def test_bench_split_of_the_semiglobal_set_under_two_gloo_ranks():
+    """bench.py --gpus 2 as the driver starts it (torch.distributed.run, one process per rank), with the CPU
+    backend and --split-only: no GPU work, only the logic that deals the fixed semi-global set to the ranks.  The
+    line must call the leg's scaling "strong", and the ranks' shares must add up to --sg-total and tile it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SA_DIST_BACKEND="gloo")
+    for total in (1001, 7):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+               "--split-only", "--sg-total", str(total)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [x for x in res.stdout.splitlines() if x.startswith("{")]
+        assert len(lines) == 1          # rank 0 alone prints
+        leg = json.loads(lines[0])["legs"]["sg_10kx11k"]
+        assert json.loads(lines[0])["n_gpus"] == 2
+        assert leg["scaling"] == "strong"
+        assert leg["pairs_all_ranks"] == total == leg["sg_total"]
+        assert leg["first_pair_this_rank"] == 0 and leg["end_of_last_shard"] == total
+        assert abs(leg["pairs_this_rank"] - total / 2) <= 1
