@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <new>
 #include <stdexcept>
 
@@ -207,27 +208,42 @@ char* runs_to_text(const uint32_t* runs, uint32_t n) {
   return out;
 }
 
-// One GPU's share of an alignment batch, or one of `mem_share` parts of it that run side by side on the
-// GPU; `threads` host threads may help with staging and text.
-int align_shard(int device, const std::vector<uint32_t>& idx, const char* const* queries,
-                const uint32_t* qlens, const char* const* targets, const uint32_t* tlens, int type,
-                int match, int mismatch, int gap, int32_t* scores, uint32_t* target_begin,
-                char** cigars, unsigned threads, unsigned mem_share) {
+// One part of a GPU's share of an alignment batch, in two phases.  `begin` stages the part's pairs through pinned
+// memory and queues everything the GPU has to do for it - copies in, the batch call, the scan of the pairs' run
+// counts, the gathering of their runs into one block, copies out - without waiting for any of it; `finish` waits,
+// scatters the results into the caller's arrays and formats the CIGAR text.  A GPU's host thread begins all its
+// parts and then finishes them in order: while it stages part k + 1 the GPU copies and aligns part k, and while
+// it formats part k's text the GPU works on the parts after it.  `threads` host threads help with staging and
+// text; `mem_share` parts hold workspaces on the GPU at once.
+struct AlignJob {
+  std::unique_ptr<Lease> lease;
+  const std::vector<uint32_t>* idx = nullptr;
+  uint64_t stride = 0;
+  bool want_cigar = false, tb_traced = false, has_tb = false;
+  StageTimer trace{0};
+};
+enum { ABUF_Q, ABUF_T, ABUF_QO, ABUF_TO, ABUF_SCORE, ABUF_TB, ABUF_NRUNS, ABUF_RUNS, ABUF_OFF, ABUF_WS, ABUF_COMPACT, ABUF_TMP };
+static_assert(ABUF_TMP < kBufs, "buffers of a context");
+
+int align_shard_begin(AlignJob& job, int device, const std::vector<uint32_t>& idx, const char* const* queries,
+                      const uint32_t* qlens, const char* const* targets, const uint32_t* tlens, int type,
+                      int match, int mismatch, int gap, bool want_target_begin, bool want_cigar, unsigned threads,
+                      unsigned mem_share) {
   const size_t n = idx.size();  // below 2^32 (checked by the caller)
+  job.idx = &idx;
   if (!n) return SA_OK;
   SA_HIP_TRY(hipSetDevice(device));
-  Lease lease(device);
-  if (!lease.c) return fail(SA_ERR_HIP, "cannot create a stream on GPU %d", device);
-  HostContext& c = *lease.c;
+  job.lease.reset(new Lease(device));
+  if (!job.lease->c) return fail(SA_ERR_HIP, "cannot create a stream on GPU %d", device);
+  HostContext& c = *job.lease->c;
   hipStream_t st = c.stream;
-  enum { Q, T, QO, TO, SCORE, TB, NRUNS, RUNS, OFF, WS, COMPACT };
-
-  StageTimer trace(device);
+  job.trace = StageTimer(device);
+  StageTimer& trace = job.trace;
   // pinned staging: offsets first, then the sequences (8 bytes of slack: the kernels read aligned 8-byte words)
   int rc;
-  if ((rc = c.pin[QO].ensure((n + 1) * 8)) || (rc = c.pin[TO].ensure((n + 1) * 8))) return rc;
-  uint64_t* hqo = c.pin[QO].as<uint64_t>();
-  uint64_t* hto = c.pin[TO].as<uint64_t>();
+  if ((rc = c.pin[ABUF_QO].ensure((n + 1) * 8)) || (rc = c.pin[ABUF_TO].ensure((n + 1) * 8))) return rc;
+  uint64_t* hqo = c.pin[ABUF_QO].as<uint64_t>();
+  uint64_t* hto = c.pin[ABUF_TO].as<uint64_t>();
   uint64_t qtot = 0, ttot = 0;
   uint32_t maxq = 0, maxt = 0, minq = ~0u, mint = ~0u;
   for (size_t j = 0; j < n; ++j) {
@@ -244,10 +260,10 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   hqo[n] = qtot;
   hto[n] = ttot;
   trace.mark("offsets");
-  if ((rc = c.pin[Q].ensure(qtot + 16)) || (rc = c.pin[T].ensure(ttot + 16))) return rc;
-  char* hq = c.pin[Q].as<char>();
-  char* ht = c.pin[T].as<char>();
-  parallel_for(n, 8192, threads, [&](size_t b, size_t e) {
+  if ((rc = c.pin[ABUF_Q].ensure(qtot + 16)) || (rc = c.pin[ABUF_T].ensure(ttot + 16))) return rc;
+  char* hq = c.pin[ABUF_Q].as<char>();
+  char* ht = c.pin[ABUF_T].as<char>();
+  parallel_for(n, 4096, threads, [&](size_t b, size_t e) {
     for (size_t j = b; j < e; ++j) {
       const uint32_t i = idx[j];
       memcpy(hq + hqo[j], queries[i], qlens[i]);
@@ -259,21 +275,24 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   trace.mark("staging");
 
   const uint64_t stride = (uint64_t)maxq + maxt;
-  const bool want_cigar = cigars != nullptr;
-  if ((rc = c.dev[Q].ensure(qtot + 16)) || (rc = c.dev[T].ensure(ttot + 16)) || (rc = c.dev[QO].ensure((n + 1) * 8)) ||
-      (rc = c.dev[TO].ensure((n + 1) * 8)) || (rc = c.dev[SCORE].ensure(n * 4)) || (rc = c.dev[TB].ensure(n * 4)))
+  job.stride = stride;
+  job.want_cigar = want_cigar;
+  if ((rc = c.dev[ABUF_Q].ensure(qtot + 16)) || (rc = c.dev[ABUF_T].ensure(ttot + 16)) ||
+      (rc = c.dev[ABUF_QO].ensure((n + 1) * 8)) || (rc = c.dev[ABUF_TO].ensure((n + 1) * 8)) ||
+      (rc = c.dev[ABUF_SCORE].ensure(n * 4)) || (rc = c.dev[ABUF_TB].ensure(n * 4)))
     return rc;
-  if (want_cigar && ((rc = c.dev[RUNS].ensure((size_t)n * stride * 4)) || (rc = c.dev[NRUNS].ensure(n * 4)))) return rc;
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[Q].p, hq, qtot + 16, hipMemcpyHostToDevice, st));
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[T].p, ht, ttot + 16, hipMemcpyHostToDevice, st));
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[QO].p, hqo, (n + 1) * 8, hipMemcpyHostToDevice, st));
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[TO].p, hto, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  if (want_cigar && ((rc = c.dev[ABUF_RUNS].ensure((size_t)n * stride * 4)) || (rc = c.dev[ABUF_NRUNS].ensure((n + 1) * 4))))
+    return rc;
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_Q].p, hq, qtot + 16, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_T].p, ht, ttot + 16, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_QO].p, hqo, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_TO].p, hto, (n + 1) * 8, hipMemcpyHostToDevice, st));
 
   sa_align_batch b{};
-  b.d_q = c.dev[Q].as<uint8_t>();
-  b.d_q_off = c.dev[QO].as<uint64_t>();
-  b.d_t = c.dev[T].as<uint8_t>();
-  b.d_t_off = c.dev[TO].as<uint64_t>();
+  b.d_q = c.dev[ABUF_Q].as<uint8_t>();
+  b.d_q_off = c.dev[ABUF_QO].as<uint64_t>();
+  b.d_t = c.dev[ABUF_T].as<uint8_t>();
+  b.d_t_off = c.dev[ABUF_TO].as<uint64_t>();
   b.n = (uint32_t)n;
   b.max_qlen = maxq;
   b.max_tlen = maxt;
@@ -283,63 +302,84 @@ int align_shard(int device, const std::vector<uint32_t>& idx, const char* const*
   b.match = match;
   b.mismatch = mismatch;
   b.gap = gap;
-  b.d_score = c.dev[SCORE].as<int32_t>();
+  b.d_score = c.dev[ABUF_SCORE].as<int32_t>();
   // Global / Semiglobal derive *target_begin from the CIGAR text; without a CIGAR the reference inspects an
   // empty string and stores 1 (src/alignment.cpp:129-136, 342-348), and no traceback is needed
-  const bool tb_traced = target_begin && (want_cigar || type == SA_LOCAL);
-  b.d_target_begin = (tb_traced || want_cigar) ? c.dev[TB].as<uint32_t>() : nullptr;
-  b.d_cigar_runs = want_cigar ? c.dev[RUNS].as<uint32_t>() : nullptr;
-  b.d_cigar_nruns = want_cigar ? c.dev[NRUNS].as<uint32_t>() : nullptr;
+  job.tb_traced = want_target_begin && (want_cigar || type == SA_LOCAL);
+  b.d_target_begin = (job.tb_traced || want_cigar) ? c.dev[ABUF_TB].as<uint32_t>() : nullptr;
+  job.has_tb = b.d_target_begin != nullptr;
+  b.d_cigar_runs = want_cigar ? c.dev[ABUF_RUNS].as<uint32_t>() : nullptr;
+  b.d_cigar_nruns = want_cigar ? c.dev[ABUF_NRUNS].as<uint32_t>() : nullptr;
   b.cigar_stride = stride;
 
   size_t min_ws = 0;
   size_t ws = sa_align_workspace_bytes(&b, &min_ws);
-  if (ws > c.dev[WS].cap) {  // a workspace kept from an earlier call serves as long as it holds one pass
+  if (ws > c.dev[ABUF_WS].cap) {  // a workspace kept from an earlier call serves as long as it holds one pass
     size_t free_b = 0, total_b = 0;
     SA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = (size_t)((free_b + c.dev[WS].cap) * 0.8 / mem_share);  // shards running side by side
+    const size_t budget = (size_t)((free_b + c.dev[ABUF_WS].cap) * 0.8 / mem_share);  // parts side by side
     if (ws > budget) ws = std::max(min_ws, budget / min_ws * min_ws);
-    if ((rc = c.dev[WS].ensure(ws))) return rc;
+    if ((rc = c.dev[ABUF_WS].ensure(ws))) return rc;
   }
   trace.mark("buffers + copies queued");
-  if ((rc = sa_align_batch_device(device, st, &b, c.dev[WS].p, c.dev[WS].cap))) return rc;
-  trace.mark("kernels queued");
+  if ((rc = sa_align_batch_device(device, st, &b, c.dev[ABUF_WS].p, c.dev[ABUF_WS].cap))) return rc;
 
-  if ((rc = c.pin[SCORE].ensure(n * 4)) || (rc = c.pin[TB].ensure(n * 4)) || (rc = c.pin[NRUNS].ensure(n * 4)))
-    return rc;
-  const int32_t* hscore = c.pin[SCORE].as<int32_t>();
-  const uint32_t* htb = c.pin[TB].as<uint32_t>();
-  const uint32_t* hnr = c.pin[NRUNS].as<uint32_t>();
-  SA_HIP_TRY(hipMemcpyAsync(c.pin[SCORE].p, c.dev[SCORE].p, n * 4, hipMemcpyDeviceToHost, st));
-  if (b.d_target_begin) SA_HIP_TRY(hipMemcpyAsync(c.pin[TB].p, c.dev[TB].p, n * 4, hipMemcpyDeviceToHost, st));
-  if (want_cigar) SA_HIP_TRY(hipMemcpyAsync(c.pin[NRUNS].p, c.dev[NRUNS].p, n * 4, hipMemcpyDeviceToHost, st));
+  if ((rc = c.pin[ABUF_SCORE].ensure(n * 4)) || (rc = c.pin[ABUF_TB].ensure(n * 4))) return rc;
+  SA_HIP_TRY(hipMemcpyAsync(c.pin[ABUF_SCORE].p, c.dev[ABUF_SCORE].p, n * 4, hipMemcpyDeviceToHost, st));
+  if (job.has_tb) SA_HIP_TRY(hipMemcpyAsync(c.pin[ABUF_TB].p, c.dev[ABUF_TB].p, n * 4, hipMemcpyDeviceToHost, st));
+  if (want_cigar) {
+    // where every pair's runs go in one block: the exclusive scan of the run counts, on the device, so that the
+    // gathering follows the traceback without a round trip to the host
+    size_t tmp_bytes = 0;
+    SA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, n + 1,
+                                       rocprim::plus<uint64_t>(), st));
+    if ((rc = c.dev[ABUF_TMP].ensure(tmp_bytes)) || (rc = c.dev[ABUF_OFF].ensure((n + 1) * 8)) ||
+        (rc = c.dev[ABUF_COMPACT].ensure((size_t)n * stride * 4)) || (rc = c.pin[ABUF_OFF].ensure((n + 1) * 8)) ||
+        (rc = c.pin[ABUF_NRUNS].ensure(n * 4)))
+      return rc;
+    SA_HIP_TRY(rocprim::exclusive_scan(c.dev[ABUF_TMP].p, tmp_bytes, c.dev[ABUF_NRUNS].as<uint32_t>(),
+                                       c.dev[ABUF_OFF].as<uint64_t>(), (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(gather_runs, dim3((uint32_t)n), dim3(64), 0, st, c.dev[ABUF_RUNS].as<uint32_t>(),
+                       c.dev[ABUF_NRUNS].as<uint32_t>(), c.dev[ABUF_OFF].as<uint64_t>(), stride, (uint32_t)n,
+                       c.dev[ABUF_COMPACT].as<uint32_t>());
+    SA_HIP_TRY(hipGetLastError());
+    SA_HIP_TRY(hipMemcpyAsync(c.pin[ABUF_OFF].p, c.dev[ABUF_OFF].p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    SA_HIP_TRY(hipMemcpyAsync(c.pin[ABUF_NRUNS].p, c.dev[ABUF_NRUNS].p, n * 4, hipMemcpyDeviceToHost, st));
+  }
+  trace.mark("kernels queued");
+  return SA_OK;
+}
+
+int align_shard_finish(AlignJob& job, int32_t* scores, uint32_t* target_begin, char** cigars, unsigned threads) {
+  if (!job.lease || !job.lease->c) return SA_OK;  // an empty part
+  const std::vector<uint32_t>& idx = *job.idx;
+  const size_t n = idx.size();
+  HostContext& c = *job.lease->c;
+  hipStream_t st = c.stream;
+  StageTimer& trace = job.trace;
+  int rc;
+  SA_HIP_TRY(hipSetDevice(c.device));
   SA_HIP_TRY(hipStreamSynchronize(st));
   trace.mark("device done");
+  const uint64_t* off = c.pin[ABUF_OFF].as<uint64_t>();
+  if (job.want_cigar) {  // the runs, now that their number is known (the copy runs under the scattering)
+    if ((rc = c.pin[ABUF_RUNS].ensure(off[n] * 4 + 4))) return rc;
+    SA_HIP_TRY(hipMemcpyAsync(c.pin[ABUF_RUNS].p, c.dev[ABUF_COMPACT].p, off[n] * 4, hipMemcpyDeviceToHost, st));
+  }
+  const int32_t* hscore = c.pin[ABUF_SCORE].as<int32_t>();
+  const uint32_t* htb = c.pin[ABUF_TB].as<uint32_t>();
   for (size_t j = 0; j < n; ++j) {
     scores[idx[j]] = hscore[j];
-    if (target_begin) target_begin[idx[j]] = tb_traced ? htb[j] : 1u;
+    if (target_begin) target_begin[idx[j]] = job.tb_traced ? htb[j] : 1u;
   }
   trace.mark("scores scattered");
-  if (want_cigar) {
-    // compact the runs on the device, then one copy back
-    if ((rc = c.pin[OFF].ensure((n + 1) * 8))) return rc;
-    uint64_t* off = c.pin[OFF].as<uint64_t>();
-    off[0] = 0;
-    for (size_t j = 0; j < n; ++j) off[j + 1] = off[j] + hnr[j];
-    if ((rc = c.dev[OFF].ensure((n + 1) * 8)) || (rc = c.dev[COMPACT].ensure(off[n] * 4)) ||
-        (rc = c.pin[RUNS].ensure(off[n] * 4)))
-      return rc;
-    SA_HIP_TRY(hipMemcpyAsync(c.dev[OFF].p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gather_runs, dim3((uint32_t)n), dim3(64), 0, st, c.dev[RUNS].as<uint32_t>(),
-                       c.dev[NRUNS].as<uint32_t>(), c.dev[OFF].as<uint64_t>(), stride, (uint32_t)n,
-                       c.dev[COMPACT].as<uint32_t>());
-    SA_HIP_TRY(hipGetLastError());
-    SA_HIP_TRY(hipMemcpyAsync(c.pin[RUNS].p, c.dev[COMPACT].p, off[n] * 4, hipMemcpyDeviceToHost, st));
+  if (job.want_cigar) {
     SA_HIP_TRY(hipStreamSynchronize(st));
     trace.mark("runs copied");
-    const uint32_t* runs = c.pin[RUNS].as<uint32_t>();
+    const uint32_t* hnr = c.pin[ABUF_NRUNS].as<uint32_t>();
+    const uint32_t* runs = c.pin[ABUF_RUNS].as<uint32_t>();
     std::atomic<bool> oom{false};
-    parallel_for(n, 4096, threads, [&](size_t b0, size_t e0) {
+    parallel_for(n, 2048, threads, [&](size_t b0, size_t e0) {
       for (size_t j = b0; j < e0; ++j) {
         cigars[idx[j]] = runs_to_text(runs + off[j], hnr[j]);
         if (!cigars[idx[j]]) oom = true;
@@ -415,6 +455,8 @@ int minimize_shard(int device, const std::vector<uint32_t>& idx, const char* con
   const int status = *c.pin[STATUS].as<int>();
   if (status == SA_ERR_RANGE)
     return fail(SA_ERR_RANGE, "decimal Minimize: a k-mer value exceeds INT_MAX (stoi out of range)");
+  if (status == SA_ERR_ARGUMENT && variant == SA_MIN_DECIMAL)
+    return fail(SA_ERR_ARGUMENT, "decimal Minimize: a sequence holds a byte other than ACGT / acgt (not supported)");
   if (status) return fail(status, "device reported status %d", status);
   if ((rc = c.pin[OUT].ensure(ooff[n] * 12 + 12))) return rc;
   const uint32_t* all = c.pin[OUT].as<uint32_t>();
@@ -592,22 +634,30 @@ int align_batch_host(const char* const* queries, const uint32_t* query_lens,
     if (!in_order)  // class members -> pair numbers
       for (auto& sh : shards)
         for (uint32_t& x : sh) x = members[x];
-    // Large shards are cut into parts that run as independent calls on streams of their own: one part's
-    // copies overlap another part's kernels, and staging and CIGAR text of the parts proceed in parallel.
+    // Large shards are cut into a few parts, each with a stream and buffers of its own: the GPU's host thread
+    // begins them one after the other and then finishes them in that order (AlignJob).
     size_t largest = 0;
     for (const auto& sh : shards) largest = std::max(largest, sh.size());
-    const unsigned parts = largest >= 262144 ? 4 : largest >= 65536 ? 2 : 1;
-    if (parts > 1) {
-      std::vector<std::vector<uint32_t>> cut;
-      for (const auto& sh : shards)
-        for (unsigned p = 0; p < parts; ++p)
-          cut.emplace_back(sh.begin() + sh.size() * p / parts, sh.begin() + sh.size() * (p + 1) / parts);
-      shards.swap(cut);
-    }
-    const unsigned threads = std::max(1u, host_threads() / (unsigned)(ndev * parts));
-    const int rc = run_on_devices(ndev * parts, [&](int task) {
-      return align_shard(device_of_shard(task / parts), shards[task], queries, query_lens, targets, target_lens, type, match,
-                         mismatch, gap, scores, target_begin, cigars, threads, parts);
+    // (measured, 150 x 300 Local with CIGAR text: 200 000 pairs 10.4 / 8.7 / 10.0 / 11.0 ms in 1 / 2 / 3 / 4 parts - a
+    // fill launch of a few ten thousand pairs takes as long as one of 400 000, its wavefronts run alone on their
+    // SIMDs - and 10^6 pairs 35.8 / 37.2 ms in 2 / 4 parts, 30.5 / 26.5 ms without text); SA_HOST_PARTS pins it
+    unsigned parts = largest >= 393216 ? 4 : largest >= 65536 ? 2 : 1;
+    if (const char* e = getenv("SA_HOST_PARTS")) parts = (unsigned)std::min(16, std::max(1, atoi(e)));
+    std::vector<std::vector<uint32_t>> cut;
+    for (const auto& sh : shards)
+      for (unsigned p = 0; p < parts; ++p)
+        cut.emplace_back(sh.begin() + sh.size() * p / parts, sh.begin() + sh.size() * (p + 1) / parts);
+    const unsigned threads = std::max(1u, host_threads() / (unsigned)ndev);
+    const int rc = run_on_devices(ndev, [&](int d) {
+      std::vector<AlignJob> jobs(parts);
+      for (unsigned p = 0; p < parts; ++p)
+        if (int r = align_shard_begin(jobs[p], device_of_shard(d), cut[(size_t)d * parts + p], queries, query_lens, targets,
+                                      target_lens, type, match, mismatch, gap, target_begin != nullptr,
+                                      cigars != nullptr, threads, parts))
+          return r;
+      for (unsigned p = 0; p < parts; ++p)
+        if (int r = align_shard_finish(jobs[p], scores, target_begin, cigars, threads)) return r;
+      return (int)SA_OK;
     });
     if (rc) return rc;
   }

@@ -520,16 +520,21 @@ struct DecStrand {
   int pre_min, pre_idx, cur_min, cur_idx;
 };
 
+// A byte other than ACGT / acgt: the reference drops such bytes from its digit strings but keeps counting windows
+// by the original length (src/minimizer.cpp:13-40, 174), so later windows see truncated k-mers and the call may
+// throw from substr / stoi; that is not reproduced - the byte is reported and the call fails.
 template <bool WRITE>
-__device__ uint32_t run_decimal(const MinArgs& a, uint32_t s, uint64_t* out, bool* range_error) {
+__device__ uint32_t run_decimal(const MinArgs& a, uint32_t s, uint64_t* out, bool* range_error, bool* other_byte) {
   const uint8_t* seq = a.seq + a.off[s];
   const uint32_t len = (uint32_t)(a.off[s + 1] - a.off[s]);
   const uint32_t k = a.k, w = a.w;
   const uint32_t windows = len - (w + k - 1) + 1;
+  uint32_t other = 0;
   auto value = [&](uint32_t x, bool fwd, int* v) -> bool {
     unsigned long long acc = 0;
     for (uint32_t t = 0; t < k; ++t) {
       const uint32_t c = base_code(seq[x + t]);
+      other |= other1(seq[x + t]);
       acc = acc * 10 + (fwd ? c : 3 - c);
     }
     *v = (int)acc;
@@ -596,15 +601,17 @@ __device__ uint32_t run_decimal(const MinArgs& a, uint32_t s, uint64_t* out, boo
     }
   }
   *range_error = !ok;
+  *other_byte = other != 0;
   return n_out;
 }
 
 __global__ __launch_bounds__(kThreads) void dec_run(MinArgs a) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.n) return;
-  bool bad = false;
-  a.chunk_count[a.chunk_base[s]] = run_decimal<true>(a, s, a.keys + a.wbase[s], &bad);  // one chunk per sequence
+  bool bad = false, other = false;
+  a.chunk_count[a.chunk_base[s]] = run_decimal<true>(a, s, a.keys + a.wbase[s], &bad, &other);  // one chunk per sequence
   if (bad && a.status) atomicMax(a.status, SA_ERR_RANGE);
+  if (other && a.status) atomicMax(a.status, SA_ERR_ARGUMENT);
 }
 
 // ---- sort / unique / output ---------------------------------------------------------------------

@@ -84,7 +84,9 @@ class DeviceMinimizeBatch:
         st = self.status()
         if st != capi.SA_OK:
             raise capi.SaError(st, "device reported %s" % {capi.SA_ERR_RANGE: "k-mer value beyond INT_MAX",
-                                                          capi.SA_ERR_CAPACITY: "output capacity exceeded"}.get(st, st))
+                                                          capi.SA_ERR_CAPACITY: "output capacity exceeded",
+                                                          capi.SA_ERR_ARGUMENT: "decimal Minimize: a byte other "
+                                                                                "than ACGT / acgt"}.get(st, st))
         off = self.d_out_off.cpu().numpy()
         out = self.d_out[: int(off[-1]) * 3].cpu().numpy().view(np.uint32).reshape(-1, 3)
         return [out[off[i]:off[i + 1]] for i in range(self.n)]

@@ -279,3 +279,22 @@ def test_single_sequence_device_wide_sort_vs_oracle(oracle):
             assert np.array_equal(minimize.minimize_binary(g, k, w), oracle.minimize_binary_array(g, k, w)), (k, w)
     finally:
         capi.set_option("no_buckets", 0)
+
+
+def test_inputs_outside_the_supported_range_fail_loudly():
+    """What the library does not reproduce is refused, never answered wrongly: MinimizeBinary with w > k + 1 or
+    k >= 32, and the decimal Minimize on a sequence with a byte other than ACGT / acgt (the reference drops such
+    bytes but keeps counting windows by the original length, src/minimizer.cpp:13-40, 174)."""
+    from sequencealigner_amd import capi, minimize
+    seq = "ACGTTGCATGCAGTCAGTCGATCGATGCATGCATGACTGACTAGCTAGCTAGTCGATGC"
+    for k, w in ((3, 5), (32, 4), (40, 2)):
+        with pytest.raises(capi.SaError) as e:
+            minimize.minimize_batch([seq], k, w, capi.SA_MIN_BINARY)
+        assert e.value.code == capi.SA_ERR_ARGUMENT
+    assert len(minimize.minimize_batch([seq], 3, 4, capi.SA_MIN_DECIMAL)[0]) > 0
+    for bad in (seq[:20] + "N" + seq[21:], seq + "n", "x" + seq):
+        with pytest.raises(capi.SaError) as e:
+            minimize.minimize_batch([seq, bad], 3, 4, capi.SA_MIN_DECIMAL)
+        assert e.value.code == capi.SA_ERR_ARGUMENT
+    # the binary variant takes such bytes (code -1, src/minimizer_binary.cpp:53-78) - see the tests above
+    assert len(minimize.minimize_batch([seq[:20] + "N" + seq[21:]], 3, 4, capi.SA_MIN_BINARY)[0]) > 0
