@@ -67,6 +67,10 @@ const char* sa_device_arch(int device);
  *   "force_coop"    (SA_FORCE_COOP)    -1 automatic, 0 / 1: cooperative wavefront kernel off / on where possible
  *   "no_tables"     (SA_NO_TABLES)     1: no kernel looks substitution scores up in tables
  *   "coop_c"        (SA_COOP_C)        columns per lane of the cooperative kernel, 0 automatic
+ *   "coop_pk"       (SA_COOP_PK)       -1 automatic, 0 / 1: the packed form of the cooperative Global / Semiglobal
+ *                                      kernel (two pairs per wavefront) off / on where it applies
+ *   "no_overlap"    (SA_NO_OVERLAP)    1: never run the traceback of a launch's first part on a second stream
+ *                                      beside the fill of the rest
  *   "coop_waves"    (SA_COOP_WAVES)    wavefronts (strips of pairs) in one pass of the cooperative Global / Semiglobal
  *                                      kernel, 64..8192 (default 8192)
  *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64
@@ -97,12 +101,15 @@ int sa_set_option(const char* name, long value);
  * hipStream_t (NULL = default stream).  d_q and d_t must be readable up to 8 bytes past their last
  * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except where
  * it runs the cooperative kernels, which synchronise the stream once at the end to read their abort flag:
- * batches of few pairs (hundreds, not thousands) of more than a few hundred symbols (kernel name
- * "wave_i32_coop", see sa_align_kernel_name), and batches of long pairs that need several passes over the
- * workspace and leave at most 768 pairs for the last pass - those pairs (and a head of few pairs) are
- * planned again as batches of their own and may take the cooperative kernels although the batch's kernel
- * name says "wave_pk16" / "wave_i32".  sa_align_may_synchronize tells which it will be for a batch and a
- * workspace size; sa_align_batch_device_static never synchronises.
+ * batches of few pairs (hundreds; up to 2048 of 4096 symbols and more) of more than a few hundred symbols
+ * (kernel names "wave_i32_coop" and "wave_pk16_coop", see sa_align_kernel_name), batches of long pairs that need
+ * several passes over the workspace and leave at most 2048 pairs for the last pass - those pairs (and a head of
+ * few pairs) are planned again as batches of their own -, and batches of long pairs of which the workspace
+ * holds fewer than 2048 wavefronts' worth at a time: these may take the cooperative kernels although the
+ * batch's kernel name says "wave_pk16" / "wave_i32".  sa_align_may_synchronize tells which it will be for a
+ * batch and a workspace size; sa_align_batch_device_static never synchronises.  Apart from that the call may
+ * use a second stream of its own beside `stream` (forked from it and joined back into it with events before the
+ * call returns its work to `stream`'s order).
  *
  * The batch is planned for max_qlen x max_tlen: every pair pays for direction words and steps of that shape.
  * Callers with mixed sizes should issue one call per size class (sa_align_batch_host does).
@@ -173,8 +180,8 @@ int sa_align_static_init(int device);
  * n, type, scoring and maximum lengths are read.  (No counterpart in the reference.) */
 int sa_align_may_synchronize(int device, const sa_align_batch* batch, size_t workspace_bytes);
 
-/* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32", "wave_i32",
- * "wave_i32_coop"), for logs and profiles. */
+/* Name of the kernel family the dispatcher picks for this shape ("lane_pk16", "lane_i32", "wave_pk16",
+ * "wave_pk16_coop", "wave_i32", "wave_i32_coop"), for logs and profiles. */
 const char* sa_align_kernel_name(const sa_align_batch* batch);
 
 /* Kernel timing for benchmarks (no counterpart in the reference).  While enabled, every
@@ -225,7 +232,9 @@ void sa_free(void* p);
  * src/utility.cpp:8-26), as uint32 triples {value, position, strand(1 = forward, 0 = other strand)};
  * sequence s owns triples [d_out_off[s], d_out_off[s+1]) of d_out.  out_capacity is in triples;
  * sa_minimize_out_capacity() gives a sufficient value.  d_status (one int, optional) receives SA_OK,
- * SA_ERR_CAPACITY or SA_ERR_RANGE, written by the device when the work completes.
+ * SA_ERR_CAPACITY, SA_ERR_RANGE or - SA_MIN_DECIMAL on a sequence with a byte other than ACGT / acgt, which the
+ * reference drops while it keeps counting windows by the original length (src/minimizer.cpp:13-40, 174); not
+ * reproduced - SA_ERR_ARGUMENT, written by the device when the work completes.
  * Requires 1 <= k <= 31, w >= 1, every length >= k + w - 1 and, for SA_MIN_BINARY, w <= k + 1; other arguments
  * are rejected with SA_ERR_ARGUMENT.  For k > 16 the values are those of the reference's 32-bit arithmetic
  * (the last 16 bases of the k-mer, src/minimizer_binary.cpp:53-78).  The limits k <= 31 and w <= k + 1 are this
