@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
   constexpr bool REL = MODE != SA_LOCAL;  // scores relative to the lane's bases
   constexpr int SH = (MODE == SA_LOCAL) ? 4 : 0;
   constexpr uint32_t STRIP = 64 * C;
-  constexpr uint32_t NB = COOP ? 16 : 64;  // steps per batch = rows per hand-over between strips
+  constexpr uint32_t NB = COOP ? 16 : 64;  // steps per batch = rows fetched at a time from the strip before (32: no gain)
   // per target position (index = position & 255, and again 256 further on, so that 16 positions from any start
   // are contiguous): both pairs' symbols in .x, or the pairs' table words
   __shared__ uint2 tring[512];
