@@ -177,6 +177,8 @@ def roofline_of(batch, typ, cells_rank, steps, ms, cnt, pmc_key=None):
         "kernel": name, "bound": "valu_int", "achieved": achieved_tops, "peak": peak_tops,
         "unit": "Tops/s (integer lane-ops; %d per cell update)" % OPS_PER_CELL[typ],
         "frac": achieved_tops / peak_tops, "traffic": None,
+        # both integer peaks, whatever the kernel computes in (a 32-bit kernel cannot exceed half the packed one)
+        "frac_of_int32_peak": achieved_tops / PEAK_I32_TOPS, "frac_of_pk16_peak": achieved_tops / PEAK_PK16_TOPS,
         "fill_ms_per_launch": fill_ms, "fill_gcups": fill_cups / 1e9,
         "launches_per_step": {"pack": cnt[0] // steps, "fill": cnt[1] // steps, "traceback": cnt[2] // steps},
         "ms_per_step_by_kernel": {"pack": ms[0] / steps, "fill": ms[1] / steps, "traceback": ms[2] / steps},

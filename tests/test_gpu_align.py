@@ -591,3 +591,35 @@ def test_packed_wavefront_kernel_tables_per_wavefront(oracle):
         for i in range(0, len(qs), 3):
             if ok[i]:
                 assert b.cigars([i])[0] == oracle.align(bytes(qs[i]), bytes(ts[i]), typ, m, x, g)[1], (typ, i)
+
+
+def test_small_workspace_sends_a_large_batch_to_the_packed_cooperative_kernel(oracle):
+    """2100 Semiglobal pairs of 4100 x 300 plan as one wavefront per two pairs; over a workspace that holds only a
+    hundred wavefronts' worth of direction words at a time that kernel would leave nine SIMDs in ten idle in every
+    pass, so the call takes the packed cooperative kernel instead (and says so: it synchronises).  Same scores
+    as the CPU checker's linear-memory scorer, CIGARs of a sample verbatim."""
+    import ctypes as C
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    n = 2100
+    rng = np.random.default_rng(77)
+    t = synth.random_bases(rng, (n, 300))
+    q = np.empty((n, 4100), np.uint8)
+    for p in range(n):
+        q[p] = synth.fit_length(rng, synth.edit(rng, np.resize(t[p], 4100), 0.05, 0.02, 0.02), 4100)
+    probe = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
+    assert probe.kernel_name() == "wave_pk16"
+    mn = C.c_size_t(0)
+    capi.lib().sa_align_workspace_bytes(C.byref(probe.batch), C.byref(mn))
+    assert capi.lib().sa_align_may_synchronize(0, C.byref(probe.batch), probe.workspace_bytes) == 0
+    del probe
+    b = align.DeviceAlignBatch(q, t, 2, 1, -1, -1, workspace_bytes=100 * mn.value)
+    assert capi.lib().sa_align_may_synchronize(0, C.byref(b.batch), b.workspace_bytes) == 1
+    b.run()
+    torch.cuda.synchronize()
+    qb, qo = synth.to_blob(q)
+    tb, to = synth.to_blob(t)
+    assert np.array_equal(b.scores(), oracle.score_linear_batch(qb, qo, tb, to, 2, 1, -1, -1, 8))
+    for i in range(0, n, 211):
+        want = oracle.align(bytes(q[i]), bytes(t[i]), 2, 1, -1, -1)
+        assert (int(b.scores()[i]), b.cigars([i])[0], int(b.target_begins()[i])) == want, i
