@@ -47,6 +47,7 @@ Options& options() {
     x->coop_waves = num("SA_COOP_WAVES", 8192);
     x->coop_pk = num("SA_COOP_PK", -1);
     x->no_overlap = num("SA_NO_OVERLAP", 0);
+    x->coop_seg_rows = num("SA_COOP_SEG_ROWS", -1);
     x->pk16_k = num("SA_PK16_K", 48);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
@@ -239,8 +240,14 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
     if (b.type != SA_LOCAL && wpk_ok && b.n >= 2 && max_q > coop_min_q && allow_coop) {
       const bool many = (uint64_t)b.n * ((max_q + 511) / 512) > 1024;
       // (tools/pkcoop.py, pairs of 10 kbp x 11 kbp: 256 pairs 8.0 ms against 13.4 on the 32-bit cooperative kernel
-      // and 50 with a wavefront per two pairs; 1024 pairs 26 against 47 and 50; 2048 pairs 50 against 93 and 52)
-      const bool few_long = force_coop < 0 && b.n <= 2048 && max_q >= 4096;
+      // and 40 with a wavefront per two pairs; 1024 pairs 18 against 47 and 42; 2048 pairs 35 against 93 and 43)
+      // Long queries: a wavefront per two pairs runs in rounds of kWavePkResident wavefronts, and a round that is
+      // not full takes the time of its fullest SIMD (one / two / three wavefronts: 0.41 / 0.70 / 1 of a full
+      // round's); the cooperative form shares the SIMDs evenly at 1.06 of a full round's time per pair (pairs of
+      // 10 kbp x 11 kbp: 3000 pairs 51 against 68 ms, 5000 pairs 84 against 99, 8192 pairs the same)
+      const double rounds = (((uint64_t)b.n + 1) / 2) / (double)kWavePkResident, part = rounds - std::floor(rounds);
+      const double alone = std::floor(rounds) + (part == 0 ? 0.0 : part <= 1 / 3.0 ? 0.41 : part <= 2 / 3.0 ? 0.70 : 1.0);
+      const bool few_long = force_coop < 0 && max_q >= 4096 && 1.06 * rounds < alone;
       pk_coop = opt.coop_pk >= 0 ? (opt.coop_pk != 0 && (coop_wanted || pk_coop_passes))
                                  : (((coop_wanted || few_long) && many) || (pk_coop_passes && force_coop != 0));
     }
@@ -250,11 +257,12 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
       const uint64_t units = ((uint64_t)b.n + 1) / 2;
       double best_time = 0;
       coop_c = 0;
+      // (more strips than the GPU holds wavefronts: they run in segments and share the SIMDs evenly)
       for (int c : {8, 10, 12, 16}) {
         const uint64_t strips = (max_q + 64 * c - 1) / (64 * c);
-        const uint64_t waves = std::min<uint64_t>(units * strips, 8192);
-        const double per_simd = std::ceil(waves / 1024.0);
-        const double time = (max_t + 63.0 + strips * 90.0) * per_simd * (9.0 * c + 30.0) * std::ceil(units * strips / (double)waves);
+        const bool shared = units * strips > kWavePkResident;
+        const double per_simd = shared ? units * strips / 1024.0 : std::ceil(units * strips / 1024.0);
+        const double time = (max_t + 63.0 + (shared ? 0.0 : strips * 90.0)) * per_simd * (9.0 * c + 30.0);
         if (!coop_c || time < best_time) {
           coop_c = c;
           best_time = time;
@@ -284,6 +292,7 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
     if (pl.coop && !pl.wave_pk && b.type != SA_LOCAL)  // one dword per lane per 16 / C steps
       pl.dirs_unit_stride = (uint64_t)pl.nstrips * (coop_steps_padded(max_t) * pl.wave_c / 16) * 64;
     pl.brow_unit_stride = (round_up((size_t)max_t + 1, 64) + 64) * 2 * (pl.coop ? 2 : 1);  // 64-bit entries
+    if (pk_coop) pl.brow_unit_stride += (uint64_t)pl.nstrips * kWaveStateSlots * 64;  // registers between segments
   } else if (pk16_ok) {
     pl.family = Family::LanePk16;
     pl.name = "lane_pk16";
@@ -719,8 +728,21 @@ int launch_wave_pk16(const Plan& pl, const AlignArgs& a, const WaveCoop& co, hip
       SA_HIP_TRY(hipMemsetAsync(co.ticket, 0, 4, stream));
       // boundary entries carry the tag of the strip that wrote them; 0 = not written in this launch
       SA_HIP_TRY(hipMemsetAsync(a.brow, 0, (size_t)units * a.brow_unit_stride * 4, stream));
+      // Strips in segments of target rows, a wavefront per segment: the strips of the launch then advance
+      // together and end together, instead of the last ones running on a GPU that empties.
+      AlignArgs x = a;
+      const long opt_rows = options().coop_seg_rows;
+      const uint32_t steps = a.max_t + 63;
+      const uint64_t strips = (uint64_t)units * a.nstrips;
+      uint32_t rows = opt_rows >= 0 ? (uint32_t)round_up((size_t)opt_rows, 64) : (strips > kWavePkResident ? kWavePkSegRows : 0u);
+      if (rows >= steps) rows = 0;
+      x.seg_rows = rows;
+      x.nseg = rows ? (uint32_t)((steps + (uint64_t)(a.nstrips - 1) * kWaveSegShift + rows - 1) / rows) : 1;
+      if (strips * x.nseg > 0x7FFFFFFFull) return fail(SA_ERR_ARGUMENT, "too many segments in a cooperative pass");
+      fill(x, (uint32_t)(strips * x.nseg));
+    } else {
+      fill(a, units);
     }
-    fill(a, COOP ? units * a.nstrips : units);
     SA_HIP_TRY(hipGetLastError());
     if (need_traceback) {
       if constexpr (COOP) {
@@ -785,7 +807,7 @@ int sa_set_option(const char* name, long value) {
     std::atomic<long>* slot;
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"coop_waves", &o.coop_waves},
-               {"coop_pk", &o.coop_pk},       {"no_overlap", &o.no_overlap},
+               {"coop_pk", &o.coop_pk}, {"coop_seg_rows", &o.coop_seg_rows},       {"no_overlap", &o.no_overlap},
                {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
@@ -1089,7 +1111,10 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
     SA_HIP_TRY(hipMemsetAsync(co.abort_flag, 0, 4, stream));
     // Wavefronts of one pass.  They need not all be resident: strips take their numbers from a ticket counter in
     // start order, so a strip only ever waits for strips that already run.
-    const size_t coop_waves = (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
+    // (The packed kernel runs the strips of a large pass in segments, all strips advancing together: its passes
+    // are as large as the workspace allows unless the option asks for less than its default.)
+    size_t coop_waves = (size_t)std::max(64L, std::min(8192L, (long)options().coop_waves));
+    if (pl.wave_pk && coop_waves == 8192) coop_waves = kWavePkPassStrips;
     const size_t cap = std::max<size_t>(1, coop_waves / pl.nstrips) * pl.pairs_per_unit;
     if (pairs_per_pass > cap) pairs_per_pass = cap;
   }

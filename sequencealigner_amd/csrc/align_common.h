@@ -44,6 +44,9 @@ struct AlignArgs {
   // cooperative kernels: set when a wait ran out; the fill's results are then incomplete and the traceback
   // kernels return at once (the call fails)
   const int* gave_up;
+  // packed cooperative kernel: target rows per segment of a strip (a multiple of 64; 0: a strip is one piece)
+  // and segments per strip
+  uint32_t seg_rows, nseg;
 };
 
 // Border values of the DP matrix, rows = target (index i), columns = query (index r).

@@ -58,6 +58,16 @@ namespace sa {
 
 constexpr int kWavePkCols = 16;  // query columns per lane (the cooperative form also runs narrower strips)
 constexpr uint32_t kWavePkCenter = 0x4000;  // Global / Semiglobal: a lane's values stay around S(base) = this
+constexpr uint32_t kWaveStateSlots = 32;   // cooperative form: dwords per lane kept between two segments of a strip
+constexpr uint32_t kWaveSegShift = 128;    // ... and the shift of the segments from one strip to the next, in steps
+// host side: wavefronts of the cooperative form the GPU holds at once (three per SIMD); a launch with more strips
+// than that runs them in segments of kWavePkSegRows steps (1024 pairs of 10 kbp x 11 kbp: 25.6 ms in one piece,
+// 21.1 / 19.0 / 17.9 / 18.2 / 20.2 ms with 4096 / 2048 / 1024 / 768 / 512; with fewer strips than that, segments that
+// wait for their predecessors take the places of ones that could run: 256 pairs 10.3 against 19 ms); strips of
+// one pass at most
+constexpr uint64_t kWavePkResident = 3072;
+constexpr uint32_t kWavePkSegRows = 1024;
+constexpr uint64_t kWavePkPassStrips = 1u << 18;
 constexpr long kWavePkMaxStep = 64;         // ... for scorings with D up to this
 
 // Direction storage: per (strip, step, lane) one uint2 - .x cells 0-7, .y cells 8-15 of the lane's
@@ -92,9 +102,12 @@ __device__ __forceinline__ uint64_t wave_pk_entry(uint32_t tag, int va, int vb) 
 __device__ __forceinline__ int wave_pk_entry_a(uint64_t e) { return (int)((uint32_t)e << 8) >> 8; }
 __device__ __forceinline__ int wave_pk_entry_b(uint64_t e) { return (int)((uint32_t)(e >> 24) << 8) >> 8; }
 
+// The work of one wavefront: two pairs (COOP: one segment of one strip of theirs, `ticket` says which).
 template <int MODE, int C, bool COOP>
-__global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, uint32_t bias, uint32_t tables) {
+__device__ __forceinline__ void wave_pk16_task(const AlignArgs& a, const WaveCoop& co, uint32_t bias, uint32_t tables,
+                                               uint32_t ticket) {
   static_assert(C <= 16 && C % 2 == 0, "one uint2 of flags per step");
+  static_assert(C + 13 < (int)kWaveStateSlots, "room for a wavefront's registers between two segments");
   static_assert(!(COOP && MODE == SA_LOCAL), "the cooperative form is Global / Semiglobal only");
   constexpr bool REL = MODE != SA_LOCAL;  // scores relative to the lane's bases
   constexpr int SH = (MODE == SA_LOCAL) ? 4 : 0;
@@ -105,12 +118,13 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
   __shared__ uint2 tring[512];
   __shared__ uint32_t seen[64];  // byte values that occur in the wavefront's sequences; then their codes
   const uint32_t lane = threadIdx.x;
-  uint32_t unit = blockIdx.x, s_mine = 0;
+  uint32_t unit = ticket, s_mine = 0, seg = 0;
+  bool results_here = true;  // COOP: the wavefront ran its strip's last segment
   if (COOP) {
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = atomicAdd(co.ticket, 1u);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    unit = ticket / a.nstrips;
+    // segment by segment over all strips of the launch, a unit's strips next to each other
+    const uint32_t per_seg = ((a.pairs_in_pass + 1) / 2) * a.nstrips;
+    seg = ticket / per_seg;
+    unit = (ticket % per_seg) / a.nstrips;
     s_mine = ticket % a.nstrips;
   }
   const uint32_t plA = 2 * unit, plB = plA + 1;
@@ -138,6 +152,15 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
   const uint32_t lastA = QA ? QA - 1 : 0, lastB = QB ? QB - 1 : 0;
   const uint32_t stripA = (QA && TA) ? lastA / STRIP : ~0u, stripB = (QB && TB) ? lastB / STRIP : ~0u;
   if (COOP && s_mine != 0 && s_mine != stripA && s_mine != stripB && s_mine >= (Q + STRIP - 1) / STRIP) return;
+  // COOP, strips in segments: segment `seg` of strip s is the steps seg_lo + 1 .. seg_lo + seg_rows that exist.  A
+  // strip needs its left neighbour's row r after that one's step r + 63 + (a batch): with the segments of strip s
+  // shifted by s * kWaveSegShift steps, a segment never waits for a later one, which keeps the order of the
+  // tickets (segment, unit, strip) free of cycles.
+  const long seg_lo = COOP ? (long)seg * a.seg_rows - (long)s_mine * (long)kWaveSegShift : 0;
+  if (COOP && a.seg_rows) {
+    if (seg != 0 && (Q == 0 || T == 0)) return;
+    if (seg_lo + (long)a.seg_rows < 1 || seg_lo + 1 > (long)T + 63) return;  // nothing of the strip in this segment
+  }
 
   if (Q != 0 && T != 0) {
     const uint32_t G = kGuard2;
@@ -154,7 +177,10 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
     const uint32_t nstrips_p = (Q + STRIP - 1) / STRIP;
     uint2* dirs = reinterpret_cast<uint2*>(a.dirs + (uint64_t)unit * a.dirs_unit_stride);
     uint64_t* bbase = reinterpret_cast<uint64_t*>(a.brow + (uint64_t)unit * a.brow_unit_stride);
-    const uint64_t bhalf = a.brow_unit_stride / 4;  // COOP: two columns of entries, used in turn
+    const uint64_t bhalf = ((a.max_t + 1 + 63) / 64 + 1) * 64;  // COOP: two columns of entries, used in turn
+    // COOP, strips in segments: behind the columns, per strip the registers of a wavefront between two segments
+    // ([kWaveStateSlots][64] dwords; the last dword: number of the segment they are ready for)
+    uint32_t* sbase = reinterpret_cast<uint32_t*>(bbase + 2 * bhalf);
     const uint32_t nsteps = a.max_t + 64;
     const uint32_t laneA = (lastA % STRIP) / C, regA = lastA % C;
     const uint32_t laneB = (lastB % STRIP) / C, regB = lastB % C;
@@ -162,7 +188,23 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
     // Do the four sequences hold at most four distinct byte values?  (seen[] becomes the byte -> code table.)
     bool use_tab = false;
     const uint8_t* codes = reinterpret_cast<const uint8_t*>(seen);
-    if (tables) {
+    uint32_t* state = sbase + (uint64_t)s_mine * (kWaveStateSlots * 64);  // COOP
+    const bool resumed = COOP && a.seg_rows && seg_lo > 0;  // a later segment: takes over the registers of the one before
+    if (resumed) {
+      // (bounded) until the wavefront of the segment before has left them
+      uint32_t* flag = state + kWaveStateSlots * 64 - 1;
+      for (uint32_t polls = 0; __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seg; ++polls) {
+        __builtin_amdgcn_s_sleep(4);
+        if (polls >= co.spin_limit ||
+            ((polls & 1023u) == 1023u && __hip_atomic_load(co.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(co.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+      seen[lane] = __builtin_nontemporal_load(state + (C + 11) * 64 + lane);  // the table of codes, if one is in use
+      use_tab = __builtin_nontemporal_load(state + (C + 12) * 64 + lane) != 0;
+      __builtin_amdgcn_wave_barrier();
+    } else if (tables) {
       alphabet_clear(seen, lane);
       alphabet_mark(seen, lane, qA, QA);
       alphabet_mark(seen, lane, tA, TA);
@@ -234,11 +276,36 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
         tring[pos & 255u] = v;
         tring[(pos & 255u) + 256u] = v;
       };
-      if (lane == 0) ring_put(0, tconv(traw(0)));
-      // a batch's inputs are fetched one batch ahead, so that no batch starts with a wait for memory
-      uint32_t t_pre = lane < NB ? traw(1 + lane) : 0u;
-      uint64_t e_pre = load_entries(1);
       const uint32_t steps = T + 63;
+      // the batches of this wavefront: all of the strip's, or those of its segment `seg`
+      uint32_t b_first = 1, b_last = steps;
+      if (COOP && a.seg_rows) {
+        b_first = seg_lo < 0 ? 1u : (uint32_t)seg_lo + 1u;
+        b_last = seg_lo + (long)a.seg_rows < (long)steps ? (uint32_t)(seg_lo + (long)a.seg_rows) : steps;
+        results_here = b_last == steps;
+      }
+      if (resumed) {
+        const uint32_t* in = state + lane;
+#pragma unroll
+        for (int k = 0; k < C; ++k) Hg[k] = __builtin_nontemporal_load(in + k * 64);
+        ldiag = __builtin_nontemporal_load(in + (C + 0) * 64);
+        lastcol = __builtin_nontemporal_load(in + (C + 1) * 64);
+        bout = __builtin_nontemporal_load(in + (C + 2) * 64);
+        baseA = (int)__builtin_nontemporal_load(in + (C + 3) * 64);
+        baseB = (int)__builtin_nontemporal_load(in + (C + 4) * 64);
+        bestA = (int)__builtin_nontemporal_load(in + (C + 5) * 64);
+        biA = __builtin_nontemporal_load(in + (C + 6) * 64);
+        bestB = (int)__builtin_nontemporal_load(in + (C + 7) * 64);
+        biB = __builtin_nontemporal_load(in + (C + 8) * 64);
+        finalA = (int)__builtin_nontemporal_load(in + (C + 9) * 64);
+        finalB = (int)__builtin_nontemporal_load(in + (C + 10) * 64);
+        ring_put(b_first - 64 + lane, tconv(traw(b_first - 64 + lane)));  // the rows the lanes are in
+      } else if (lane == 0) {
+        ring_put(0, tconv(traw(0)));
+      }
+      // a batch's inputs are fetched one batch ahead, so that no batch starts with a wait for memory
+      uint32_t t_pre = lane < NB ? traw(b_first + lane) : 0u;
+      uint64_t e_pre = load_entries(b_first);
       uint2* drow = dirs + (uint64_t)s * nsteps * 64 + lane;
       uint32_t pick_mask[C];  // wave-uniform: which half of which column holds a pair's last column
 #pragma unroll
@@ -411,7 +478,7 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
           if (FETCH && X == 15) asm volatile("" ::"v"(t_pre), "v"(e_pre));  // (the wait for the loads comes here)
         });
       };
-      for (uint32_t b0 = 1; b0 <= steps; b0 += NB) {  // batches of NB steps
+      for (uint32_t b0 = b_first; b0 <= b_last; b0 += NB) {  // batches of NB steps
         if (lane < NB) ring_put(b0 + lane, tconv(t_pre));  // target positions b0 .. b0 + NB - 1
         uint64_t entry = e_pre;
         const bool full = b0 >= 64 && b0 + NB - 1 <= T;  // every lane has a row in every step of the batch
@@ -484,6 +551,27 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
           for (uint32_t st = b0; st <= e; ++st) step(b0, st);
         }
       }
+      if (COOP && !results_here) {  // the registers, for the wavefront of the next segment
+        uint32_t* out = state + lane;
+#pragma unroll
+        for (int k = 0; k < C; ++k) __builtin_nontemporal_store(Hg[k], out + k * 64);
+        __builtin_nontemporal_store(ldiag, out + (C + 0) * 64);
+        __builtin_nontemporal_store(lastcol, out + (C + 1) * 64);
+        __builtin_nontemporal_store(bout, out + (C + 2) * 64);
+        __builtin_nontemporal_store((uint32_t)baseA, out + (C + 3) * 64);
+        __builtin_nontemporal_store((uint32_t)baseB, out + (C + 4) * 64);
+        __builtin_nontemporal_store((uint32_t)bestA, out + (C + 5) * 64);
+        __builtin_nontemporal_store(biA, out + (C + 6) * 64);
+        __builtin_nontemporal_store((uint32_t)bestB, out + (C + 7) * 64);
+        __builtin_nontemporal_store(biB, out + (C + 8) * 64);
+        __builtin_nontemporal_store((uint32_t)finalA, out + (C + 9) * 64);
+        __builtin_nontemporal_store((uint32_t)finalB, out + (C + 10) * 64);
+        __builtin_nontemporal_store(seen[lane], out + (C + 11) * 64);
+        __builtin_nontemporal_store(TAB ? 1u : 0u, out + (C + 12) * 64);
+        __threadfence();
+        if (lane == 63)
+          __hip_atomic_store(state + kWaveStateSlots * 64 - 1, seg + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (MODE == SA_LOCAL) {  // the strip's candidates against the lane's: higher score, then smaller row
         const int scA = (int)((skey & 0x7FF0u) >> 4) - (int)bias, scB = (int)((skey >> 20) & 0x7FFu) - (int)bias;
         if (scA > bestA || (scA == bestA && scA > 0 && siA < biA)) {
@@ -528,7 +616,7 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
     finalB = __builtin_amdgcn_readlane(finalB, laneB);
     }
   }
-  if (lane != 0) return;
+  if (lane != 0 || !results_here) return;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h == 1 && !hasB) break;
@@ -560,6 +648,22 @@ __global__ __launch_bounds__(64) void fill_wave_pk16(AlignArgs a, WaveCoop co, u
     a.end_i[pl] = bi;
     a.end_r[pl] = br;
   }
+}
+
+// One wavefront per two pairs; COOP: per ticket, (segment, unit, strip) in this order, in the order in which the
+// wavefronts start.  A wavefront only ever waits for the work of an earlier ticket, which is done or with a
+// wavefront that runs, so the launch ends however few of its wavefronts the GPU holds at a time.
+// (Three wavefronts per SIMD: left to itself the compiler takes a few registers too many for the cooperative form
+// with sixteen columns and the GPU then holds two; held to three it spills a few pointers before and after the
+// strip's loop, none inside.)
+template <int MODE, int C, bool COOP>
+__global__ __launch_bounds__(64, 3) void fill_wave_pk16(AlignArgs a, WaveCoop co, uint32_t bias, uint32_t tables) {
+  uint32_t ticket = blockIdx.x;
+  if (COOP) {
+    if (threadIdx.x == 0) ticket = atomicAdd(co.ticket, 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+  }
+  wave_pk16_task<MODE, C, COOP>(a, co, bias, tables, ticket);
 }
 
 }  // namespace sa

@@ -39,7 +39,10 @@ def _force_family(name):
     """Pins the kernel family the dispatcher may choose ("lane": the inter-pair lane kernels, packed
     16-bit where exact, else 32-bit; "wave": one pair per wavefront); None restores automatic choice."""
     from sequencealigner_amd import capi
-    family, coop, i32, coop_pk = 0, -1, 0, -1
+    family, coop, i32, coop_pk, seg = 0, -1, 0, -1, -1
+    if name == "cooppkseg":  # as "cooppk", every strip in segments of 64 target rows, a wavefront per segment
+        seg = 64
+        name = "cooppk"
     if name == "wave32":    # one wave per pair, 32-bit scores only
         i32 = 1
         name = "wave"
@@ -56,9 +59,10 @@ def _force_family(name):
     capi.set_option("force_coop", coop)
     capi.set_option("force_i32", i32)
     capi.set_option("coop_pk", coop_pk)
+    capi.set_option("coop_seg_rows", seg)
 
 
-@pytest.fixture(params=["auto", "lane", "wave", "wave32", "coop", "cooppk"])
+@pytest.fixture(params=["auto", "lane", "wave", "wave32", "coop", "cooppk", "cooppkseg"])
 def family(request):
     _force_family(None if request.param == "auto" else request.param)
     yield request.param
@@ -283,7 +287,7 @@ def test_full_size_properties():
     assert ((tb + t_used) <= 300).all()
 
 
-@pytest.fixture(params=["wave", "wave32", "coop", "cooppk"])
+@pytest.fixture(params=["wave", "wave32", "coop", "cooppk", "cooppkseg"])
 def wave_mode(request):
     _force_family(request.param)
     yield request.param
@@ -301,8 +305,8 @@ def test_long_pairs_vs_oracle(oracle, wave_mode):
         assert len(cases) == 6
         b = align.DeviceAlignBatch([c["q"] for c in cases], [c["t"] for c in cases], typ, m, x, g)
         packed = wave_mode == "wave" and typ != 1   # Global / Semiglobal within the 16-bit window
-        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" or (wave_mode == "cooppk" and typ == 1) else
-                                   "wave_pk16_coop" if wave_mode == "cooppk" else
+        assert b.kernel_name() == ("wave_i32_coop" if wave_mode == "coop" or (wave_mode.startswith("cooppk") and typ == 1) else
+                                   "wave_pk16_coop" if wave_mode.startswith("cooppk") else
                                    "wave_pk16" if packed else "wave_i32")
         _run_group(cases)
     # one pair with unequal lengths, crossing a strip boundary exactly (2048 columns) and not (2049)
@@ -348,7 +352,7 @@ def test_local_ties_across_strips_vs_oracle(oracle):
     t[15:20] = b"TTTTT"
     want = oracle.align(bytes(q), bytes(t), 1, 1, -1, -1)
     assert want == (5, "5M", 15)
-    for fam in ("wave", "wave32", "coop", "cooppk", "lane", None):
+    for fam in ("wave", "wave32", "coop", "cooppk", "cooppkseg", "lane", None):
         _force_family(fam)
         try:
             s, c, tb = align.align_batch([bytes(q)], [bytes(t)], 1, 1, -1, -1)
@@ -594,7 +598,7 @@ def test_packed_wavefront_kernel_tables_per_wavefront(oracle):
 
 
 def test_small_workspace_sends_a_large_batch_to_the_packed_cooperative_kernel(oracle):
-    """2100 Semiglobal pairs of 4100 x 300 plan as one wavefront per two pairs; over a workspace that holds only a
+    """2100 Semiglobal pairs of 4000 x 300 plan as one wavefront per two pairs; over a workspace that holds only a
     hundred wavefronts' worth of direction words at a time that kernel would leave nine SIMDs in ten idle in every
     pass, so the call takes the packed cooperative kernel instead (and says so: it synchronises).  Same scores
     as the CPU checker's linear-memory scorer, CIGARs of a sample verbatim."""
@@ -604,9 +608,9 @@ def test_small_workspace_sends_a_large_batch_to_the_packed_cooperative_kernel(or
     n = 2100
     rng = np.random.default_rng(77)
     t = synth.random_bases(rng, (n, 300))
-    q = np.empty((n, 4100), np.uint8)
+    q = np.empty((n, 4000), np.uint8)
     for p in range(n):
-        q[p] = synth.fit_length(rng, synth.edit(rng, np.resize(t[p], 4100), 0.05, 0.02, 0.02), 4100)
+        q[p] = synth.fit_length(rng, synth.edit(rng, np.resize(t[p], 4000), 0.05, 0.02, 0.02), 4000)
     probe = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
     assert probe.kernel_name() == "wave_pk16"
     mn = C.c_size_t(0)

@@ -153,7 +153,8 @@ def test_config5_global_100k_x_100k_single_pair(oracle):
 def test_long_pairs_on_the_packed_wavefront_kernels(oracle, length, target_len, n):
     """Global and Semiglobal pairs of 20 kbp x 22 kbp and 40 kbp x 44 kbp (matrix values from -84 000 along the
     borders to +30 000 on the path: far outside 15 bits) on the packed 16-bit wavefront kernel, which keeps every lane's scores relative
-    to a base of its own, in both forms: one wavefront per two pairs, and one per (two pairs, strip).  Every
+    to a base of its own, in its forms: one wavefront per two pairs, one per (two pairs, strip), and one per (two
+    pairs, strip, segment of 1024 target rows) as a launch with more strips than the GPU holds wavefronts runs.  Every
     score equals the CPU checker's linear-memory scorer, every CIGAR re-scores to it, consumes the aligned spans
     and has M on equal and X on unequal symbols; at 20 kbp the first pair of each type equals the CPU checker's
     full-matrix result verbatim.  Pairs of a batch differ in length (the two pairs of a wavefront then end in
@@ -175,9 +176,10 @@ def test_long_pairs_on_the_packed_wavefront_kernels(oracle, length, target_len, 
     for typ in (0, 2):
         want = oracle.score_linear_batch(qb, qo, tb, to, typ, 1, -1, -1, 8)
         full = oracle.align(qs[0], ts[0], typ, 1, -1, -1) if length <= 20_000 else None
-        for name, coop, pk in (("wave_pk16", 0, -1), ("wave_pk16_coop", 1, 1)):
+        for name, coop, pk, seg in (("wave_pk16", 0, -1, -1), ("wave_pk16_coop", 1, 1, -1), ("wave_pk16_coop", 1, 1, 1024)):
             capi.set_option("force_coop", coop)
             capi.set_option("coop_pk", pk)
+            capi.set_option("coop_seg_rows", seg)
             try:
                 b = align.DeviceAlignBatch(qs, ts, typ, 1, -1, -1)
                 assert b.kernel_name() == name
@@ -186,8 +188,9 @@ def test_long_pairs_on_the_packed_wavefront_kernels(oracle, length, target_len, 
             finally:
                 capi.set_option("force_coop", -1)
                 capi.set_option("coop_pk", -1)
+                capi.set_option("coop_seg_rows", -1)
             scores = b.scores()
-            assert np.array_equal(scores, want), (typ, name)
+            assert np.array_equal(scores, want), (typ, name, seg)
             nruns = b.d_nruns[:n].cpu().numpy()
             runs = b.d_runs.cpu().numpy().view(np.uint32).reshape(n, b.stride)
             rs, qu, tu = _rescore(runs, nruns, b.stride, 1, -1, -1)
