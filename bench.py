@@ -319,7 +319,7 @@ def leg_sg_10k(lib, dev, steps, warmup, threads, with_cpu, n, first=0, world=Non
            "steps": steps, "passes_per_step": cnt[1] // steps,
            "workspace_GB": b.workspace_bytes / 1e9,
            "cigars_rescore_to_score": ok, "query_consumed_min_max": [qmin, qmax],
-           "roofline": roofline_of(b, typ, cells, steps, ms, cnt, "fill_wave_pk16<2, 16, false>")}
+           "roofline": roofline_of(b, typ, cells, steps, ms, cnt, "fill_wave_pk16<2, ")}  # (the only leg with these kernels)
     if with_cpu:
         sample = min(n, max(threads, 16))
         q = q_dev[:sample].cpu().numpy()

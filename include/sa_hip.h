@@ -72,7 +72,11 @@ const char* sa_device_arch(int device);
  *   "no_overlap"    (SA_NO_OVERLAP)    1: never run the traceback of a launch's first part on a second stream
  *                                      beside the fill of the rest
  *   "coop_waves"    (SA_COOP_WAVES)    wavefronts (strips of pairs) in one pass of the cooperative Global / Semiglobal
- *                                      kernel, 64..8192 (default 8192)
+ *                                      kernels, 64..8192 (default 8192: the packed kernel then takes what the
+ *                                      workspace holds, up to 2^18 strips)
+ *   "coop_seg_rows" (SA_COOP_SEG_ROWS) packed cooperative kernel: target rows per segment of a strip (one wavefront
+ *                                      per segment), -1 automatic (1024 when a pass has more than 3072 strips,
+ *                                      else whole strips), 0 whole strips
  *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64
  *   "min_chunk"     (SA_MIN_CHUNK)     windows per minimizer chunk, 0 automatic
  *   "no_buckets"    (SA_NO_BUCKETS)    1: a single sequence is sorted by the device-wide radix sort, as sequences
@@ -101,7 +105,8 @@ int sa_set_option(const char* name, long value);
  * hipStream_t (NULL = default stream).  d_q and d_t must be readable up to 8 bytes past their last
  * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except where
  * it runs the cooperative kernels, which synchronise the stream once at the end to read their abort flag:
- * batches of few pairs (hundreds; up to 2048 of 4096 symbols and more) of more than a few hundred symbols
+ * batches of few pairs (hundreds) of more than a few hundred symbols, Global / Semiglobal batches of any size with
+ * queries of 2048 symbols and more unless a wavefront per two pairs fills the GPU in whole rounds about as well
  * (kernel names "wave_i32_coop" and "wave_pk16_coop", see sa_align_kernel_name), batches of long pairs that need
  * several passes over the workspace and leave at most 2048 pairs for the last pass - those pairs (and a head of
  * few pairs) are planned again as batches of their own -, and batches of long pairs of which the workspace

@@ -243,11 +243,13 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
       // and 40 with a wavefront per two pairs; 1024 pairs 18 against 47 and 42; 2048 pairs 35 against 93 and 43)
       // Long queries: a wavefront per two pairs runs in rounds of kWavePkResident wavefronts, and a round that is
       // not full takes the time of its fullest SIMD (one / two / three wavefronts: 0.41 / 0.70 / 1 of a full
-      // round's); the cooperative form shares the SIMDs evenly at 1.06 of a full round's time per pair (pairs of
-      // 10 kbp x 11 kbp: 3000 pairs 51 against 68 ms, 5000 pairs 84 against 99, 8192 pairs the same)
+      // round's); the cooperative form, its strips in segments, shares the SIMDs evenly at about the rate of full
+      // rounds (tools/pkcoop.py, call: 3000 pairs of 10 kbp x 11 kbp 48 against 69 ms, 6144 pairs 90 against 87;
+      // 9000 pairs of 3000 x 3300 14.5 against 16.6, 6144 pairs 10.4 against 10.3; 8000 pairs of 2000 x 2200 6.4
+      // against 6.9; 30 000 pairs of 1200 x 1300 13.8 against 13.0 - its traceback does not run under the fill)
       const double rounds = (((uint64_t)b.n + 1) / 2) / (double)kWavePkResident, part = rounds - std::floor(rounds);
       const double alone = std::floor(rounds) + (part == 0 ? 0.0 : part <= 1 / 3.0 ? 0.41 : part <= 2 / 3.0 ? 0.70 : 1.0);
-      const bool few_long = force_coop < 0 && max_q >= 4096 && 1.06 * rounds < alone;
+      const bool few_long = force_coop < 0 && max_q >= 2048 && 1.03 * rounds < alone;
       pk_coop = opt.coop_pk >= 0 ? (opt.coop_pk != 0 && (coop_wanted || pk_coop_passes))
                                  : (((coop_wanted || few_long) && many) || (pk_coop_passes && force_coop != 0));
     }

@@ -41,10 +41,22 @@
 // made absolute again (base + relative value) by the lane that holds them.  Local keeps absolute scores (its
 // clamp at zero needs them) and with them its bound on the score.
 //
-// COOP: one wavefront per (two pairs, strip), all strips of the launch resident at once, strip numbers from a
-// ticket counter; the boundary column goes through memory 16 rows at a time as 64-bit entries {tag of the
-// writing strip, both pairs' values as 24-bit numbers}, written and polled with single device-scope accesses
-// (the protocol of align_wave_i32.h).  For the few long pairs that cannot fill the GPU with a wavefront each.
+// COOP: one wavefront per (two pairs, strip), strip numbers from a ticket counter; the boundary column goes
+// through memory 16 rows at a time as 64-bit entries {tag of the writing strip, both pairs' values as 24-bit
+// numbers}, written and polled with single device-scope accesses (the protocol of align_wave_i32.h).  For long
+// pairs that cannot fill the GPU evenly with a wavefront each.
+// A launch with more strips than the GPU holds wavefronts cuts every strip into segments of target rows, one
+// wavefront per (segment, two pairs, strip), tickets in this order: a wavefront stops after its segment's last
+// step, with its lanes in 64 different rows as they are, leaves its registers (the columns' values, the lanes'
+// bases, the values collected for the next strip, the best last-column scores so far, the table of symbol
+// codes) in memory behind the boundary columns and a flag after them; the wavefront of the next segment waits
+// for the flag, takes the registers, fills the ring of target symbols with the 64 rows in flight and goes on
+// with the next step - the steps and their results are those of the strip in one piece.  All strips of the
+// launch then advance at the same pace, segment by segment, and end together; in one piece the strips that start
+// last run on a GPU that empties while each waits for its left neighbour on a fuller SIMD (1024 pairs of 10 kbp
+// x 11 kbp: 25.6 ms in one piece, 17.9 in segments).  The segments of strip s lie s * 128 steps earlier than
+// those of strip 0: the rows a segment needs from the strip to its left are then all written by that strip's
+// segment of the same number or an earlier one, so no wavefront waits for a ticket later than its own.
 //
 // Preconditions (checked on the host): gap <= 0, mismatch <= match, gap <= match; Global / Semiglobal:
 // D <= 64 and every score within 24 bits; Local: gap < 0, mismatch < 0, every value within an 11-bit window.
