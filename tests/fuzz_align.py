@@ -36,7 +36,7 @@ def main():
     t_end = time.time() + args.seconds
     batches = pairs_checked = 0
     while time.time() < t_end:
-        fam = rng.choice([None, "lane", "wave", "wave32", "coop"])
+        fam = rng.choice([None, "lane", "wave", "wave32", "coop", "coop"])
         capi.set_option("force_i32", 1 if fam == "wave32" else 0)
         capi.set_option("force_family", {None: 0, "lane": 1}.get(fam, 2))
         capi.set_option("force_coop", 1 if fam == "coop" else 0 if fam in ("wave", "wave32") else -1)
@@ -48,6 +48,9 @@ def main():
         capi.set_option("seg_cap", 8 if short_segments and rng.random() < 0.2 else 0)
         # and with few wavefronts per pass, so that a batch takes several passes
         capi.set_option("coop_waves", rng.choice([64, 256, 8192]) if fam == "coop" else 8192)
+        # in the packed form where it applies, its strips in one piece or in segments of 64 .. 256 target rows
+        capi.set_option("coop_pk", rng.choice([-1, 0, 1, 1]) if fam == "coop" else -1)
+        capi.set_option("coop_seg_rows", rng.choice([-1, 0, 64, 64, 128, 256]) if fam == "coop" else -1)
         typ = rng.choice([0, 1, 2])
         match, mismatch, gap = rng.choice([0, 1, 1, 2, 3]), rng.choice([-3, -2, -1, -1, 0, 1]), rng.choice([-3, -2, -1, -1, 0, 1])
         big = rng.random() < 0.15
