@@ -627,3 +627,31 @@ def test_small_workspace_sends_a_large_batch_to_the_packed_cooperative_kernel(or
     for i in range(0, n, 211):
         want = oracle.align(bytes(q[i]), bytes(t[i]), 2, 1, -1, -1)
         assert (int(b.scores()[i]), b.cigars([i])[0], int(b.target_begins()[i])) == want, i
+
+
+def test_a_launch_with_more_strips_than_wavefronts_runs_in_segments(oracle):
+    """3400 Semiglobal pairs of 2100 x 1400 (ragged): 1700 units of three strips each, more strips than the GPU holds
+    wavefronts of the packed cooperative kernel, so the dispatcher's own choice is that kernel with every strip cut
+    into segments of 1024 target rows (two per strip here, the second one short).  Every score equals the CPU
+    checker's linear-memory scorer, a sample of pairs its full result verbatim."""
+    import torch
+    from sequencealigner_amd import align, synth
+    n = 3400
+    rng = np.random.default_rng(2100)
+    qs, ts = [], []
+    for p in range(n):
+        t = synth.random_bases(rng, 1400 - (p % 7) * 13)
+        src = np.resize(t, 2100)
+        q = synth.fit_length(rng, synth.edit(rng, src, 0.04, 0.03, 0.03), 2100 - (p % 5) * 31)
+        qs.append(bytes(q))
+        ts.append(bytes(t))
+    b = align.DeviceAlignBatch(qs, ts, 2, 1, -1, -1)
+    assert b.kernel_name() == "wave_pk16_coop"
+    b.run()
+    torch.cuda.synchronize()
+    qb, qo = synth.to_blob(qs)
+    tb, to = synth.to_blob(ts)
+    assert np.array_equal(b.scores(), oracle.score_linear_batch(qb, qo, tb, to, 2, 1, -1, -1, 8))
+    for i in range(0, n, 487):
+        want = oracle.align(qs[i], ts[i], 2, 1, -1, -1)
+        assert (int(b.scores()[i]), b.cigars([i])[0], int(b.target_begins()[i])) == want, i
