@@ -215,6 +215,7 @@ __device__ __forceinline__ void wave_pk16_task(const AlignArgs& a, const WaveCoo
       }
       seen[lane] = __builtin_nontemporal_load(state + (C + 11) * 64 + lane);  // the table of codes, if one is in use
       use_tab = __builtin_nontemporal_load(state + (C + 12) * 64 + lane) != 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the table is read by every lane)
       __builtin_amdgcn_wave_barrier();
     } else if (tables) {
       alphabet_clear(seen, lane);
@@ -312,6 +313,8 @@ __device__ __forceinline__ void wave_pk16_task(const AlignArgs& a, const WaveCoo
         finalA = (int)__builtin_nontemporal_load(in + (C + 9) * 64);
         finalB = (int)__builtin_nontemporal_load(in + (C + 10) * 64);
         ring_put(b_first - 64 + lane, tconv(traw(b_first - 64 + lane)));  // the rows the lanes are in
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (other lanes read them)
+        __builtin_amdgcn_wave_barrier();
       } else if (lane == 0) {
         ring_put(0, tconv(traw(0)));
       }
