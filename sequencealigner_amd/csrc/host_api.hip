@@ -239,17 +239,14 @@ int align_shard_begin(AlignJob& job, int device, const std::vector<uint32_t>& id
   hipStream_t st = c.stream;
   job.trace = StageTimer(device);
   StageTimer& trace = job.trace;
-  // pinned staging: offsets first, then the sequences (8 bytes of slack: the kernels read aligned 8-byte words)
+  // Pinned staging, ONE block - both offset arrays, then the queries, then the targets (16 bytes of slack each:
+  // the kernels read aligned 8-byte words) - which goes to the device in one copy: four copies on a stream start
+  // a good hundred microseconds apart each, and a part's kernels wait for the last of them.
   int rc;
-  if ((rc = c.pin[ABUF_QO].ensure((n + 1) * 8)) || (rc = c.pin[ABUF_TO].ensure((n + 1) * 8))) return rc;
-  uint64_t* hqo = c.pin[ABUF_QO].as<uint64_t>();
-  uint64_t* hto = c.pin[ABUF_TO].as<uint64_t>();
   uint64_t qtot = 0, ttot = 0;
   uint32_t maxq = 0, maxt = 0, minq = ~0u, mint = ~0u;
   for (size_t j = 0; j < n; ++j) {
     const uint32_t i = idx[j];
-    hqo[j] = qtot;
-    hto[j] = ttot;
     qtot += qlens[i];
     ttot += tlens[i];
     maxq = std::max(maxq, qlens[i]);
@@ -257,12 +254,27 @@ int align_shard_begin(AlignJob& job, int device, const std::vector<uint32_t>& id
     minq = std::min(minq, qlens[i]);
     mint = std::min(mint, tlens[i]);
   }
-  hqo[n] = qtot;
-  hto[n] = ttot;
+  const size_t at_qo = 0, at_to = (n + 1) * 8, at_q = 2 * (n + 1) * 8, at_t = round_up(at_q + qtot + 16, 256);
+  const size_t in_bytes = at_t + ttot + 16;
+  if ((rc = c.pin[ABUF_Q].ensure(in_bytes))) return rc;
+  char* hin = c.pin[ABUF_Q].as<char>();
+  uint64_t* hqo = reinterpret_cast<uint64_t*>(hin + at_qo);
+  uint64_t* hto = reinterpret_cast<uint64_t*>(hin + at_to);
+  {
+    uint64_t qa = 0, ta = 0;
+    for (size_t j = 0; j < n; ++j) {
+      const uint32_t i = idx[j];
+      hqo[j] = qa;
+      hto[j] = ta;
+      qa += qlens[i];
+      ta += tlens[i];
+    }
+    hqo[n] = qa;
+    hto[n] = ta;
+  }
   trace.mark("offsets");
-  if ((rc = c.pin[ABUF_Q].ensure(qtot + 16)) || (rc = c.pin[ABUF_T].ensure(ttot + 16))) return rc;
-  char* hq = c.pin[ABUF_Q].as<char>();
-  char* ht = c.pin[ABUF_T].as<char>();
+  char* hq = hin + at_q;
+  char* ht = hin + at_t;
   parallel_for(n, 4096, threads, [&](size_t b, size_t e) {
     for (size_t j = b; j < e; ++j) {
       const uint32_t i = idx[j];
@@ -277,22 +289,18 @@ int align_shard_begin(AlignJob& job, int device, const std::vector<uint32_t>& id
   const uint64_t stride = (uint64_t)maxq + maxt;
   job.stride = stride;
   job.want_cigar = want_cigar;
-  if ((rc = c.dev[ABUF_Q].ensure(qtot + 16)) || (rc = c.dev[ABUF_T].ensure(ttot + 16)) ||
-      (rc = c.dev[ABUF_QO].ensure((n + 1) * 8)) || (rc = c.dev[ABUF_TO].ensure((n + 1) * 8)) ||
-      (rc = c.dev[ABUF_SCORE].ensure(n * 4)) || (rc = c.dev[ABUF_TB].ensure(n * 4)))
+  if ((rc = c.dev[ABUF_Q].ensure(in_bytes)) || (rc = c.dev[ABUF_SCORE].ensure(n * 4)) || (rc = c.dev[ABUF_TB].ensure(n * 4)))
     return rc;
   if (want_cigar && ((rc = c.dev[ABUF_RUNS].ensure((size_t)n * stride * 4)) || (rc = c.dev[ABUF_NRUNS].ensure((n + 1) * 4))))
     return rc;
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_Q].p, hq, qtot + 16, hipMemcpyHostToDevice, st));
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_T].p, ht, ttot + 16, hipMemcpyHostToDevice, st));
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_QO].p, hqo, (n + 1) * 8, hipMemcpyHostToDevice, st));
-  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_TO].p, hto, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  SA_HIP_TRY(hipMemcpyAsync(c.dev[ABUF_Q].p, hin, in_bytes, hipMemcpyHostToDevice, st));
+  char* din = c.dev[ABUF_Q].as<char>();
 
   sa_align_batch b{};
-  b.d_q = c.dev[ABUF_Q].as<uint8_t>();
-  b.d_q_off = c.dev[ABUF_QO].as<uint64_t>();
-  b.d_t = c.dev[ABUF_T].as<uint8_t>();
-  b.d_t_off = c.dev[ABUF_TO].as<uint64_t>();
+  b.d_q = reinterpret_cast<uint8_t*>(din + at_q);
+  b.d_q_off = reinterpret_cast<uint64_t*>(din + at_qo);
+  b.d_t = reinterpret_cast<uint8_t*>(din + at_t);
+  b.d_t_off = reinterpret_cast<uint64_t*>(din + at_to);
   b.n = (uint32_t)n;
   b.max_qlen = maxq;
   b.max_tlen = maxt;
