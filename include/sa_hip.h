@@ -106,7 +106,7 @@ int sa_set_option(const char* name, long value);
  * offset (symbols are fetched 4 or 8 at a time).  The call only enqueues work on the stream, except where
  * it runs the cooperative kernels, which synchronise the stream once at the end to read their abort flag:
  * batches of few pairs (hundreds) of more than a few hundred symbols, Global / Semiglobal batches of any size with
- * queries of 2048 symbols and more unless a wavefront per two pairs fills the GPU in whole rounds about as well
+ * queries of 1800 symbols and more unless a wavefront per two pairs fills the GPU in whole rounds about as well
  * (kernel names "wave_i32_coop" and "wave_pk16_coop", see sa_align_kernel_name), batches of long pairs that need
  * several passes over the workspace and leave at most 2048 pairs for the last pass - those pairs (and a head of
  * few pairs) are planned again as batches of their own -, and batches of long pairs of which the workspace

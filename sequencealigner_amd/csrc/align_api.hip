@@ -249,7 +249,7 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
       // against 6.9; 30 000 pairs of 1200 x 1300 13.8 against 13.0 - its traceback does not run under the fill)
       const double rounds = (((uint64_t)b.n + 1) / 2) / (double)kWavePkResident, part = rounds - std::floor(rounds);
       const double alone = std::floor(rounds) + (part == 0 ? 0.0 : part <= 1 / 3.0 ? 0.41 : part <= 2 / 3.0 ? 0.70 : 1.0);
-      const bool few_long = force_coop < 0 && max_q >= 2048 && 1.03 * rounds < alone;
+      const bool few_long = force_coop < 0 && max_q >= 1800 && 1.03 * rounds < alone;
       pk_coop = opt.coop_pk >= 0 ? (opt.coop_pk != 0 && (coop_wanted || pk_coop_passes))
                                  : (((coop_wanted || few_long) && many) || (pk_coop_passes && force_coop != 0));
     }

@@ -598,7 +598,7 @@ def test_packed_wavefront_kernel_tables_per_wavefront(oracle):
 
 
 def test_small_workspace_sends_a_large_batch_to_the_packed_cooperative_kernel(oracle):
-    """2100 Semiglobal pairs of 2000 x 300 plan as one wavefront per two pairs; over a workspace that holds only a
+    """2100 Semiglobal pairs of 1500 x 300 plan as one wavefront per two pairs; over a workspace that holds only a
     hundred wavefronts' worth of direction words at a time that kernel would leave nine SIMDs in ten idle in every
     pass, so the call takes the packed cooperative kernel instead (and says so: it synchronises).  Same scores
     as the CPU checker's linear-memory scorer, CIGARs of a sample verbatim."""
@@ -608,9 +608,9 @@ def test_small_workspace_sends_a_large_batch_to_the_packed_cooperative_kernel(or
     n = 2100
     rng = np.random.default_rng(77)
     t = synth.random_bases(rng, (n, 300))
-    q = np.empty((n, 2000), np.uint8)
+    q = np.empty((n, 1500), np.uint8)
     for p in range(n):
-        q[p] = synth.fit_length(rng, synth.edit(rng, np.resize(t[p], 2000), 0.05, 0.02, 0.02), 2000)
+        q[p] = synth.fit_length(rng, synth.edit(rng, np.resize(t[p], 1500), 0.05, 0.02, 0.02), 1500)
     probe = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
     assert probe.kernel_name() == "wave_pk16"
     mn = C.c_size_t(0)
