@@ -48,7 +48,7 @@ Options& options() {
     x->coop_pk = num("SA_COOP_PK", -1);
     x->no_overlap = num("SA_NO_OVERLAP", 0);
     x->coop_seg_rows = num("SA_COOP_SEG_ROWS", -1);
-    x->pk16_k = num("SA_PK16_K", 48);
+    x->pk16_k = num("SA_PK16_K", 0);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
     x->no_segments = num("SA_NO_SEGMENTS", 0);
@@ -145,9 +145,17 @@ bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
   return true;
 }
 
-int pk16_strip_rows() {
+// Rows per strip of the packed lane kernel: 48 keeps three wavefronts per SIMD, 64 two - about 3 % fewer cells per
+// second - but the target is padded to whole strips: 300 rows are 336 in strips of 48 and 320 in strips of 64 (10^6
+// Local pairs of 150 x 300: 9.46-9.50 ms with 48, 9.30-9.35 with 64; 32: 9.8, its launch is not cut where the
+// traceback could run beside it).  The option "pk16_k" pins it.
+int pk16_strip_rows(const sa_align_batch& b) {
   const long v = options().pk16_k;
-  return (v == 32 || v == 48 || v == 64) ? (int)v : 48;
+  if (v == 32 || v == 48 || v == 64) return (int)v;
+  const double t = b.max_tlen ? b.max_tlen : 1;
+  const double rows48 = std::ceil(t / 48.0) * 48.0, rows64 = std::ceil(t / 64.0) * 64.0 * 1.03;
+  uint32_t unused = 0;
+  return (rows64 < rows48 && lane_pk16_applicable(b, 64, &unused)) ? 64 : 48;
 }
 
 // pk_coop_passes: the caller's workspace holds so few pairs of this batch at a time that the one-wavefront-per-
@@ -156,7 +164,7 @@ Plan make_plan(const sa_align_batch& b, bool allow_coop = true, bool pk_coop_pas
   Plan pl{};
   const uint32_t max_q = b.max_qlen ? b.max_qlen : 1, max_t = b.max_tlen ? b.max_tlen : 1;
   uint32_t bias = 0;
-  const int K16 = pk16_strip_rows();
+  const int K16 = pk16_strip_rows(b);
   const Options& opt = options();
   const bool force_i32 = opt.force_i32 != 0;
   const long force_family = opt.force_family;  // 1 lane, 2 wave

@@ -47,7 +47,7 @@ struct Options {
   std::atomic<long> coop_pk{-1};      // SA_COOP_PK: -1 automatic, 0 / 1 pin the packed form of the cooperative Global /
                                       // Semiglobal kernel (two pairs per wavefront) where it applies
   std::atomic<long> no_overlap{0};    // SA_NO_OVERLAP: never run a traceback on a second stream under the fill's last round
-  std::atomic<long> pk16_k{48};       // SA_PK16_K: rows per strip of the packed lane kernel (32, 48, 64)
+  std::atomic<long> pk16_k{0};        // SA_PK16_K: rows per strip of the packed lane kernel (32, 48, 64; 0 automatic)
   std::atomic<long> min_chunk{0};     // SA_MIN_CHUNK: windows per minimizer chunk (0 automatic, 8..4096)
   std::atomic<long> no_buckets{0};    // SA_NO_BUCKETS: single sequences take the device-wide radix sort
   std::atomic<long> no_segments{0};   // SA_NO_SEGMENTS: long pairs are traced back by one wavefront each
