@@ -77,8 +77,8 @@ const char* sa_device_arch(int device);
  *   "coop_seg_rows" (SA_COOP_SEG_ROWS) packed cooperative kernel: target rows per segment of a strip (one wavefront
  *                                      per segment), -1 automatic (1024 when a pass has more than 3072 strips,
  *                                      else whole strips), 0 whole strips
- *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64; 0 automatic (48, or 64
- *                                      where that pads the targets to fewer rows)
+ *   "pk16_k"        (SA_PK16_K)        rows per strip of the packed lane kernel: 32, 48 or 64; 0 automatic (48 or 64,
+ *                                      by the rows and the strips the targets then take)
  *   "min_chunk"     (SA_MIN_CHUNK)     windows per minimizer chunk, 0 automatic
  *   "no_buckets"    (SA_NO_BUCKETS)    1: a single sequence is sorted by the device-wide radix sort, as sequences
  *                                      beyond 32 M windows always are

@@ -146,16 +146,20 @@ bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
 }
 
 // Rows per strip of the packed lane kernel: 48 keeps three wavefronts per SIMD, 64 two - about 3 % fewer cells per
-// second - but the target is padded to whole strips: 300 rows are 336 in strips of 48 and 320 in strips of 64 (10^6
-// Local pairs of 150 x 300: 9.46-9.50 ms with 48, 9.30-9.35 with 64; 32: 9.8, its launch is not cut where the
-// traceback could run beside it).  The option "pk16_k" pins it.
+// second - but fewer strips walk the query, and every strip pays for reading and writing the boundary row and for
+// its own start: about what seven rows cost (the last strip has 16, 32 or 48 rows either way).  10^6 Local pairs of
+// 150 x 300, seven strips of 48 rows or five of 64: 9.46-9.50 against 9.30-9.35 ms, which is where the seven comes
+// from; strips of 32 rows: 9.8 ms.  The option "pk16_k" pins the height.
 int pk16_strip_rows(const sa_align_batch& b) {
   const long v = options().pk16_k;
   if (v == 32 || v == 48 || v == 64) return (int)v;
-  const double t = b.max_tlen ? b.max_tlen : 1;
-  const double rows48 = std::ceil(t / 48.0) * 48.0, rows64 = std::ceil(t / 64.0) * 64.0 * 1.03;
+  const uint32_t t = b.max_tlen ? b.max_tlen : 1;
+  auto cost = [&](uint32_t k, double per_row) {
+    const uint32_t nfull = t / k, rem = t - nfull * k;
+    return (nfull * k + (rem + 15) / 16 * 16) * per_row + 7.0 * (nfull + (rem ? 1 : 0));
+  };
   uint32_t unused = 0;
-  return (rows64 < rows48 && lane_pk16_applicable(b, 64, &unused)) ? 64 : 48;
+  return (cost(64, 1.03) < cost(48, 1.0) && lane_pk16_applicable(b, 64, &unused)) ? 64 : 48;
 }
 
 // pk_coop_passes: the caller's workspace holds so few pairs of this batch at a time that the one-wavefront-per-
