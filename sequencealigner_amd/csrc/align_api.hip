@@ -145,21 +145,34 @@ bool wave_pk16_applicable(const sa_align_batch& b, uint32_t* bias_out) {
   return true;
 }
 
-// Rows per strip of the packed lane kernel: 48 keeps three wavefronts per SIMD, 64 two - about 3 % fewer cells per
-// second - but fewer strips walk the query, and every strip pays for reading and writing the boundary row and for
-// its own start: about what seven rows cost (the last strip has 16, 32 or 48 rows either way).  10^6 Local pairs of
-// 150 x 300, seven strips of 48 rows or five of 64: 9.46-9.50 against 9.30-9.35 ms, which is where the seven comes
-// from; strips of 32 rows: 9.8 ms.  The option "pk16_k" pins the height.
+// Rows per strip of the packed lane kernel, 48 or 64.  An estimate of the fill's time decides:
+//   (rows the strips cover + 7 per strip) x (rounds of the launch's wavefronts),
+// the last strip having 16, 32 or 48 rows either way, every strip paying about seven rows' worth for reading and
+// writing the boundary row and for its own start, strips of 64 rows costing 3 % more per row; the GPU holds 3 / 2
+// (Local) or 2 / 1 (Global, Semiglobal) wavefronts per SIMD with strips of 48 / 64 rows, and a round with 1 / 2 / 3
+// wavefronts on its fullest SIMD takes 1.22 / 2.1 / 3 times a lone wavefront's time.  Measured, strips of 48
+// against 64 (ms): 10^6 Local pairs of 150 x 300 9.48 / 9.35 (what the 0.96 below is fitted to), of 150 x 150
+// 5.23 / 5.18, of 100 x 200 4.48 / 4.51; 4 10^5 of 150 x 100 2.38 / 2.11; 3 10^5 Global 250 x 400 7.96 / 8.48;
+// 10^5 Semiglobal 500 x 600 8.38 / 7.82 - the estimate picks the faster in all but the third (0.6 % apart).
+// Strips of 32 rows: 9.8 ms on the first.  The option "pk16_k" pins the height.
 int pk16_strip_rows(const sa_align_batch& b) {
   const long v = options().pk16_k;
   if (v == 32 || v == 48 || v == 64) return (int)v;
   const uint32_t t = b.max_tlen ? b.max_tlen : 1;
-  auto cost = [&](uint32_t k, double per_row) {
+  const uint64_t units = ((uint64_t)b.n + 127) / 128;
+  auto estimate = [&](uint32_t k, double per_row, uint32_t per_simd) {
     const uint32_t nfull = t / k, rem = t - nfull * k;
-    return (nfull * k + (rem + 15) / 16 * 16) * per_row + 7.0 * (nfull + (rem ? 1 : 0));
+    const double unit = (nfull * k + (rem + 15) / 16 * 16) * per_row + 7.0 * (nfull + (rem ? 1 : 0));
+    const double round_time[4] = {0.0, 1.22, 2.1, 3.0};
+    const uint64_t resident = 1024ull * per_simd, full = units / resident, rest = units - full * resident;
+    return unit * (full * round_time[per_simd] + round_time[(rest + 1023) / 1024]);
   };
+  const bool local = b.type == SA_LOCAL;
   uint32_t unused = 0;
-  return (cost(64, 1.03) < cost(48, 1.0) && lane_pk16_applicable(b, 64, &unused)) ? 64 : 48;
+  return (0.96 * estimate(64, 1.03, local ? 2 : 1) < estimate(48, 1.0, local ? 3 : 2) &&
+          lane_pk16_applicable(b, 64, &unused))
+             ? 64
+             : 48;
 }
 
 // pk_coop_passes: the caller's workspace holds so few pairs of this batch at a time that the one-wavefront-per-
