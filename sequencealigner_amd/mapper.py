@@ -11,6 +11,8 @@ command line defaults to gap 0 and no CIGAR (src/mapper.cpp:467-468) - sequencea
 mapper's values.  A read shorter than k + w - 1 bases has no window: the reference's loop bound underflows
 there (src/minimizer_binary.cpp:161, outside its defined behaviour); here such a read simply has no minimizers
 and therefore no chain, and the other reads of the file are unaffected."""
+import threading
+
 import numpy as np
 import torch
 
@@ -53,12 +55,25 @@ def _run_classes(idx, qlens, tlens, make_batch, cigars, block, device):
     side = torch.cuda.Stream(device) if has_rest else None
     if side is not None:
         side.wait_stream(torch.cuda.current_stream(device))  # the batches' inputs were made on the current stream
-    for n_cls, (_, batch) in enumerate(batches):
-        # the rare sizes last: their call waits for its kernels (cooperative kernel), the others only enqueue
-        if side is not None and n_cls == len(batches) - 1:
-            batch.run(side)
-        else:
-            batch.run()
+    # A call that takes the cooperative kernels waits for them (it reads their abort flag), and both the rare sizes
+    # and a class of reads of a few thousand bases do: the rare sizes' call runs in a thread of its own (the
+    # library call releases the interpreter lock), so that the two batches share the GPU instead of following
+    # each other.
+    worker, failed = None, []
+    if side is not None:
+        def run_rest(batch=batches[-1][1]):
+            try:
+                batch.run(side)
+            except Exception as e:  # noqa: BLE001 - handed to the caller's thread below
+                failed.append(e)
+        worker = threading.Thread(target=run_rest)
+        worker.start()
+    for _, batch in (batches[:-1] if side is not None else batches):
+        batch.run()
+    if worker is not None:
+        worker.join()
+        if failed:
+            raise failed[0]
     torch.cuda.synchronize(device)
     for sel, batch in batches:
         bl, _ = batch.cigar_stats()

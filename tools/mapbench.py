@@ -9,6 +9,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -81,11 +82,16 @@ def main():
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
         t0 = time.perf_counter()
-        for n_cls, batch in enumerate(batches):
-            if side is not None and n_cls == len(batches) - 1:
-                batch.run(side)   # few pairs of rare sizes: on a stream of their own beside the large classes
-            else:
-                batch.run()
+        # few pairs of rare sizes: on a stream of their own beside the large classes, their call in a thread of its
+        # own (calls that take the cooperative kernels wait for them; see sequencealigner_amd/mapper.py)
+        worker = None
+        if side is not None:
+            worker = threading.Thread(target=batches[-1].run, args=(side,))
+            worker.start()
+        for batch in (batches[:-1] if side is not None else batches):
+            batch.run()
+        if worker is not None:
+            worker.join()
         torch.cuda.synchronize()
         t["align"] = time.perf_counter() - t0
         t0 = time.perf_counter()
