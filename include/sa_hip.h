@@ -30,6 +30,10 @@ enum { SA_GLOBAL = 0, SA_LOCAL = 1, SA_SEMIGLOBAL = 2 };
 /* Value returned as "score" for an unknown alignment type (reference src/alignment.cpp:371-373). */
 #define SA_UNKNOWN_TYPE_SCORE 9999
 
+/* Score of every pair of a batch whose cooperative kernels gave up waiting, with the option "coop_async" (no
+ * counterpart in the reference; no alignment has this score). */
+#define SA_SCORE_GAVE_UP (-2147483647 - 1)
+
 /* CIGAR run encoding on the device: (length << 2) | op, op 0='M' 1='X' 2='I' 3='D'
  * (same four letters as reference src/alignment.cpp:104-119). */
 #define SA_OP_M 0u
@@ -74,6 +78,10 @@ const char* sa_device_arch(int device);
  *   "coop_waves"    (SA_COOP_WAVES)    wavefronts (strips of pairs) in one pass of the cooperative Global / Semiglobal
  *                                      kernels, 64..8192 (default 8192: the packed kernel then takes what the
  *                                      workspace holds, up to 2^18 strips)
+ *   "coop_async"    (SA_COOP_ASYNC)    1: a call that runs the cooperative kernels only enqueues, like every other
+ *                                      call (sa_align_may_synchronize then answers 0); should one of the kernels'
+ *                                      bounded waits run out, every score of the batch is SA_SCORE_GAVE_UP and the
+ *                                      other outputs are undefined, instead of the call failing with SA_ERR_HIP
  *   "coop_seg_rows" (SA_COOP_SEG_ROWS) packed cooperative kernel: target rows per segment of a strip (one wavefront
  *                                      per segment), -1 automatic (1024 when a pass has more than 3072 strips,
  *                                      else whole strips), 0 whole strips

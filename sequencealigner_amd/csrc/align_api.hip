@@ -48,6 +48,7 @@ Options& options() {
     x->coop_pk = num("SA_COOP_PK", -1);
     x->no_overlap = num("SA_NO_OVERLAP", 0);
     x->coop_seg_rows = num("SA_COOP_SEG_ROWS", -1);
+    x->coop_async = num("SA_COOP_ASYNC", 0);
     x->pk16_k = num("SA_PK16_K", 0);
     x->min_chunk = num("SA_MIN_CHUNK", 0);
     x->no_buckets = num("SA_NO_BUCKETS", 0);
@@ -422,6 +423,13 @@ __global__ __launch_bounds__(256) void cigar_stats_kernel(uint32_t n, const uint
 __global__ void clear_words(uint32_t* p, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
+}
+
+// Option "coop_async": a call that ran the cooperative kernels does not wait for them; if one of their bounded
+// waits ran out, every score of the batch becomes SA_SCORE_GAVE_UP instead.
+__global__ void mark_scores_if_gave_up(const int* gave_up, int32_t* score, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) score[i] = SA_SCORE_GAVE_UP;
 }
 
 // A second stream for a call: the traceback of the pairs whose fill has finished runs there while the last,
@@ -834,7 +842,7 @@ int sa_set_option(const char* name, long value) {
     std::atomic<long>* slot;
   } table[] = {{"force_i32", &o.force_i32},   {"force_family", &o.force_family}, {"force_coop", &o.force_coop},
                {"no_tables", &o.no_tables},   {"coop_c", &o.coop_c},             {"coop_waves", &o.coop_waves},
-               {"coop_pk", &o.coop_pk}, {"coop_seg_rows", &o.coop_seg_rows},       {"no_overlap", &o.no_overlap},
+               {"coop_pk", &o.coop_pk}, {"coop_seg_rows", &o.coop_seg_rows}, {"coop_async", &o.coop_async},       {"no_overlap", &o.no_overlap},
                {"pk16_k", &o.pk16_k},
                {"min_chunk", &o.min_chunk},   {"fake_devices", &o.fake_devices},
                {"no_buckets", &o.no_buckets}, {"no_segments", &o.no_segments}, {"seg_rows", &o.seg_rows},
@@ -990,7 +998,7 @@ size_t leftover_pairs(const Plan& pl, const sa_align_batch& b, size_t pairs_per_
 // Whether align_batch_device would run cooperative kernels (and therefore synchronise the stream) for this batch
 // over a workspace of this size: directly, or for the head or the left-over pairs of a several-pass batch.
 bool batch_synchronises(const sa_align_batch& b, size_t workspace_bytes, int device) {
-  if (b.n == 0 || b.type < 0 || b.type > 2) return false;
+  if (b.n == 0 || b.type < 0 || b.type > 2 || options().coop_async) return false;
   const Plan pl = plan_for_workspace(b, true, workspace_bytes, device);
   if (pl.coop) return true;
   if (workspace_bytes < pl.bytes_per_block + kFixedWorkspace) return false;  // the call fails before any launch
@@ -1167,7 +1175,11 @@ int align_batch_device(int device, void* stream_, const sa_align_batch* b, void*
       rc = launch_pass<SA_SEMIGLOBAL>(pl, a, co, qpk, tpk, alpha, stream, need_tb, overlap_device);
     if (rc) return rc;
   }
-  if (pl.coop) {  // the cooperative kernels report a wait that ran out through a flag
+  if (pl.coop && options().coop_async) {
+    hipLaunchKernelGGL(mark_scores_if_gave_up, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream, co.abort_flag,
+                       b->d_score, (uint32_t)b->n);
+    SA_HIP_TRY(hipGetLastError());
+  } else if (pl.coop) {  // the cooperative kernels report a wait that ran out through a flag
     int aborted = 0;
     SA_HIP_TRY(hipMemcpyAsync(&aborted, co.abort_flag, 4, hipMemcpyDeviceToHost, stream));
     SA_HIP_TRY(hipStreamSynchronize(stream));

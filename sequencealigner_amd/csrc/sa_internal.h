@@ -43,6 +43,7 @@ struct Options {
   std::atomic<long> coop_waves{8192}; // SA_COOP_WAVES: wavefronts of one pass of the cooperative Global /
                                       // Semiglobal kernel (64..8192)
   std::atomic<long> coop_c{0};        // SA_COOP_C: columns per lane of the cooperative kernel (0 automatic)
+  std::atomic<long> coop_async{0};      // SA_COOP_ASYNC: 1: calls that run the cooperative kernels do not wait for them
   std::atomic<long> coop_seg_rows{-1};  // SA_COOP_SEG_ROWS: target rows per segment of the packed cooperative kernel's strips (-1 automatic, 0 none)
   std::atomic<long> coop_pk{-1};      // SA_COOP_PK: -1 automatic, 0 / 1 pin the packed form of the cooperative Global /
                                       // Semiglobal kernel (two pairs per wavefront) where it applies

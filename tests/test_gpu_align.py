@@ -494,6 +494,60 @@ def test_cooperative_wait_that_runs_out_fails_the_call(oracle):
         assert (int(b.scores()[0]), b.cigars([0])[0], int(b.target_begins()[0])) == want
 
 
+def test_cooperative_calls_that_only_enqueue(oracle):
+    """With the option coop_async a call that runs the cooperative kernels does not wait for them:
+    sa_align_may_synchronize answers 0, the results are the usual ones, and a wait that runs out (the bound at one
+    poll, a host-side option; the kernels still run to their end) shows as the marker score in every pair of the
+    batch instead of a failed call."""
+    import ctypes as C
+    import torch
+    from sequencealigner_amd import align, capi, synth
+    rng = np.random.default_rng(12)
+    qs, ts = [], []
+    for p in range(6):
+        t = synth.random_bases(rng, 5200 - 100 * p)
+        qs.append(bytes(synth.fit_length(rng, synth.edit(rng, t[:4800], 0.04, 0.03, 0.03), 4800 - 50 * p)))
+        ts.append(bytes(t))
+    capi.set_option("coop_async", 1)
+    try:
+        for typ in (0, 2):
+            b = align.DeviceAlignBatch(qs, ts, typ, 1, -1, -1)
+            assert b.kernel_name().endswith("_coop")
+            assert capi.lib().sa_align_may_synchronize(0, C.byref(b.batch), b.workspace_bytes) == 0
+            capi.set_option("spin_limit", 1)
+            try:
+                b.run()   # returns without an error
+            finally:
+                capi.set_option("spin_limit", 1 << 24)
+            torch.cuda.synchronize()
+            assert (b.scores() == -2**31).all()
+            b.run()
+            torch.cuda.synchronize()
+            for i in range(6):
+                want = oracle.align(qs[i], ts[i], typ, 1, -1, -1)
+                assert (int(b.scores()[i]), b.cigars([i])[0], int(b.target_begins()[i])) == want, (typ, i)
+        # the packed cooperative kernel: 128 pairs, scores against the linear-memory scorer
+        t = synth.random_bases(rng, (128, 4400))
+        q = np.stack([synth.fit_length(rng, synth.edit(rng, t[p, :4300], 0.04, 0.03, 0.03), 4300) for p in range(128)])
+        b = align.DeviceAlignBatch(q, t, 2, 1, -1, -1)
+        assert b.kernel_name() == "wave_pk16_coop"
+        assert capi.lib().sa_align_may_synchronize(0, C.byref(b.batch), b.workspace_bytes) == 0
+        capi.set_option("spin_limit", 1)
+        try:
+            b.run()
+        finally:
+            capi.set_option("spin_limit", 1 << 24)
+        torch.cuda.synchronize()
+        assert (b.scores() == -2**31).all()
+        b.run()
+        torch.cuda.synchronize()
+        qb, qo = synth.to_blob(q)
+        tb, to = synth.to_blob(t)
+        assert np.array_equal(b.scores(), oracle.score_linear_batch(qb, qo, tb, to, 2, 1, -1, -1, 8))
+    finally:
+        capi.set_option("coop_async", 0)
+
+
 def test_empty_and_odd_batches_vs_oracle(oracle, family):
     """Empty queries / targets next to ordinary pairs, and batches of 1 and 3 pairs (a packed wavefront or
     lane then holds a pair without a partner); the meaning of the empty cases is the one the CPU
